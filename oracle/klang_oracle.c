@@ -1,0 +1,626 @@
+/*
+ * klang_oracle.c -- CPU restatement of atheler/klang's per-block DSP hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT (see klang_oracle.h).  Scalar float64,
+ * reference operation order, build with -O2 -ffp-contract=off.
+ * Citations are file:line relative to the reference root.
+ */
+#include "klang_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static const double KO_PI = 3.141592653589793;           /* klang/constants.py:5 */
+static const double KO_TAU = 2. * 3.141592653589793;      /* klang/constants.py:8 */
+static const double KO_DT = 1. / KO_SAMPLING_RATE;        /* klang/audio/helpers.py:9 */
+static const double KO_INTERVAL = (1. / KO_SAMPLING_RATE) * KO_BUFFER_SIZE; /* helpers.py:12 */
+
+/* ------------------------------------------------------------------------ */
+/* NumPy's float remainder (np.mod / Python %): C fmod, then the result takes
+ * the divisor's sign.  Used by oscillators.py:66, waves.py:34,39, math.py:11. */
+double ko_np_mod(double a, double b)
+{
+    double m = fmod(a, b);
+    if (b == 0.)
+        return m;
+    if (m != 0.) {
+        if ((b < 0.) != (m < 0.))
+            m += b;
+    } else {
+        m = copysign(0., b);
+    }
+    return m;
+}
+
+/* oscillators.py:57-60,66-67 (scalar frequency branch).
+ * t = DT * arange(257) (helpers.py:28-32); phase = (TAU*f)*t + start; mod TAU. */
+void ko_sample_phase_const(double frequency, double start, double *phase, double *next)
+{
+    const double w = KO_TAU * frequency;
+    for (int n = 0; n <= KO_BUFFER_SIZE; ++n) {
+        const double t = KO_DT * (double)n;
+        const double p = ko_np_mod(w * t + start, KO_TAU);
+        if (n < KO_BUFFER_SIZE)
+            phase[n] = p;
+        else
+            *next = p;
+    }
+}
+
+/* oscillators.py:61-67 (array frequency branch): phase[0] = start;
+ * phase[1:] = (TAU*DT) * cumsum(f) + start.  np.cumsum on float64 is a plain
+ * sequential running sum. */
+void ko_sample_phase_array(const double *frequency, double start, double *phase, double *next)
+{
+    const double k = KO_TAU * KO_DT;
+    double running = 0.;
+    phase[0] = ko_np_mod(start, KO_TAU);
+    for (int n = 1; n <= KO_BUFFER_SIZE; ++n) {
+        running = (n == 1) ? frequency[0] : running + frequency[n - 1];
+        const double p = ko_np_mod(k * running + start, KO_TAU);
+        if (n < KO_BUFFER_SIZE)
+            phase[n] = p;
+        else
+            *next = p;
+    }
+}
+
+/* oscillators.py:91-96 (Phasor.sample; also Lfo scalar shape :175-177). */
+double ko_phasor_step(double frequency, double current)
+{
+    return ko_np_mod(KO_TAU * frequency * KO_INTERVAL + current, KO_TAU);
+}
+
+/* math.py:9-11 */
+double ko_wrap(double phase)
+{
+    return ko_np_mod(phase + KO_PI, KO_TAU) - KO_PI;
+}
+
+/* waves.py:22-39; oscillators.py:259-260 for PWM. */
+void ko_wave(int wave_id, const double *phase, size_t n, double duty, double *out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const double p = phase[i];
+        double v;
+        switch (wave_id) {
+        case KO_WAVE_SINE:
+            v = sin(p);
+            break;
+        case KO_WAVE_SQUARE:
+            v = 2. * (ko_wrap(p) >= 0. ? 1. : 0.) - 1.;
+            break;
+        case KO_WAVE_SAWTOOTH:
+            v = 2. * ko_np_mod(p, KO_TAU) / KO_TAU - 1.;
+            break;
+        case KO_WAVE_TRIANGLE:
+            v = 1. - fabs(ko_np_mod(4. * ko_wrap(p) / KO_TAU, 4.) - 2.);
+            break;
+        case KO_WAVE_PWM:
+            v = 2. * (p < KO_TAU * duty ? 1. : 0.) - 1.;
+            break;
+        default:
+            v = 1.;
+            break;
+        }
+        out[i] = v;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* _envelope.c:112-119 */
+double ko_env_coefficient(double rate, double overshoot)
+{
+    if (rate <= 0.)
+        return 0.;
+    return exp(-log((1.0 + overshoot) / overshoot) / rate);
+}
+
+/* _envelope.c:187-198 */
+void ko_envelope_recompute(ko_envelope *e)
+{
+    e->attackCoef = ko_env_coefficient(e->attack / e->dt, e->overshoot);
+    e->attackBase = (1. + e->overshoot) * (1. - e->attackCoef);
+    e->decayCoef = ko_env_coefficient(e->decay / e->dt, e->overshoot);
+    e->decayBase = (e->sustain - e->overshoot) * (1. - e->decayCoef);
+    e->releaseCoef = ko_env_coefficient(e->release / e->dt, e->overshoot);
+    e->releaseBase = (0. - e->overshoot) * (1. - e->releaseCoef);
+}
+
+/* _envelope.c:461-490 (defaults), :518-535 (init incl. overshoot clip :532) */
+void ko_envelope_init(ko_envelope *e, double attack, double decay, double sustain,
+                      double release, double dt, double overshoot, int retrigger, int loop)
+{
+    e->attack = attack;
+    e->decay = decay;
+    e->sustain = sustain;
+    e->release = release;
+    e->dt = dt;
+    e->overshoot = fmin(fmax(overshoot, 1e-9), 1e9);
+    e->retrigger = retrigger != 0;
+    e->loop = loop != 0;
+    e->stage = KO_OFF;
+    e->value = 0.;
+    e->enabled = 0;
+    ko_envelope_recompute(e);
+}
+
+/* _envelope.c:549-567 */
+void ko_envelope_gate(ko_envelope *e, int on)
+{
+    if (on) {
+        e->enabled = 1;
+        if (e->retrigger || e->stage == KO_OFF || e->stage == KO_RELEASING)
+            e->stage = KO_ATTACKING;
+    } else {
+        e->enabled = 0;
+        if (e->stage == KO_ATTACKING || e->stage == KO_DECAYING || e->stage == KO_SUSTAINING)
+            e->stage = KO_RELEASING;
+    }
+}
+
+/* _envelope.c:579-624 */
+double ko_envelope_step(ko_envelope *e)
+{
+    double v = 0.;
+    switch (e->stage) {
+    case KO_OFF:
+        v = 0.;
+        break;
+    case KO_ATTACKING:
+        v = e->attackBase + e->value * e->attackCoef;
+        if (v >= 1.) {
+            v = 1.;
+            e->stage = KO_DECAYING;
+        }
+        break;
+    case KO_DECAYING:
+        v = e->decayBase + e->value * e->decayCoef;
+        if (v <= e->sustain) {
+            v = e->sustain;
+            e->stage = e->loop ? KO_RELEASING : KO_SUSTAINING;
+        }
+        break;
+    case KO_SUSTAINING:
+        v = e->sustain;
+        break;
+    case KO_RELEASING:
+        v = e->releaseBase + e->value * e->releaseCoef;
+        if (v <= 0.) {
+            v = 0.;
+            e->stage = (e->loop && e->enabled) ? KO_ATTACKING : KO_OFF;
+        }
+        break;
+    }
+    e->value = v;
+    return v;
+}
+
+/* _envelope.c:636-663 */
+void ko_envelope_sample(ko_envelope *e, size_t n, double *out)
+{
+    for (size_t i = 0; i < n; ++i)
+        out[i] = ko_envelope_step(e);
+}
+
+/* ------------------------------------------------------------------------ */
+/* effects.py:266-269, 354: scipy.signal.butter(N=2, Wn, btype='lowpass').
+ * scipy is an un-vendored dependency (requirements.txt:2, no version pin;
+ * fixtures were made with scipy 1.15.3).  Published algorithm: 2nd-order
+ * Butterworth analog prototype, frequency pre-warp, bilinear transform.  With
+ * K = tan(pi*Wn/2):  b = K^2/(1+sqrt2 K+K^2) * [1,2,1],
+ * a = [1, 2(K^2-1)/(..), (1-sqrt2 K+K^2)/(..)].  Agrees with scipy's
+ * zpk->tf route to <= 2e-15 relative (tests/test_oracle_golden.py). */
+void ko_butter2_lowpass(double wn, double b[3], double a[3])
+{
+    const double K = tan(KO_PI * wn / 2.);
+    const double K2 = K * K;
+    const double r2 = sqrt(2.);
+    const double norm = 1. / (1. + r2 * K + K2);
+    b[0] = K2 * norm;
+    b[1] = 2. * b[0];
+    b[2] = b[0];
+    a[0] = 1.;
+    a[1] = 2. * (K2 - 1.) * norm;
+    a[2] = (1. - r2 * K + K2) * norm;
+}
+
+/* effects.py:260-265: np.logspace(log2(20), log2(20000), num=1000, base=2).
+ * np.linspace computes arange(num)*step + start with the last point forced to
+ * stop; logspace is power(base, y). */
+void ko_filter_grid(double *freqs)
+{
+    const double start = log2(20.);
+    const double stop = log2(20000.);
+    const double step = (stop - start) / (double)(KO_GRID_POINTS - 1);
+    for (int i = 0; i < KO_GRID_POINTS; ++i) {
+        double y = (double)i * step + start;
+        if (i == KO_GRID_POINTS - 1)
+            y = stop;
+        freqs[i] = pow(2., y);
+    }
+}
+
+/* effects.py:271-274: np.searchsorted (side='left') then clip to [0, n-1]. */
+int ko_filter_grid_index(const double *freqs, int n, double frequency)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (freqs[mid] < frequency)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo > n - 1)
+        lo = n - 1;
+    return lo;
+}
+
+/* effects.py:309-316: scipy.signal.lfilter(b, a, x, zi) for len(b)=len(a)=3,
+ * a[0]=1.  scipy's direct-form-II-transposed loop:
+ *   y = z0 + b0*x;  z0 = z1 + b1*x - a1*y;  z1 = b2*x - a2*y. */
+void ko_lfilter2(const double b[3], const double a[3], const double *x, size_t n,
+                 double z[2], double *y)
+{
+    double z0 = z[0], z1 = z[1];
+    for (size_t i = 0; i < n; ++i) {
+        const double xi = x[i];
+        const double yi = z0 + b[0] * xi;
+        z0 = z1 + b[1] * xi - a[1] * yi;
+        z1 = b[2] * xi - a[2] * yi;
+        y[i] = yi;
+    }
+    z[0] = z0;
+    z[1] = z1;
+}
+
+/* effects.py:128 (Tremolo): lfilter with b=[b0], a=[1,a1] -> scipy pads b to
+ * len 2: y = z0 + b0*x; z0 = 0*x - a1*y. */
+void ko_lfilter1(const double b[1], const double a[2], const double *x, size_t n,
+                 double z[1], double *y)
+{
+    double z0 = z[0];
+    for (size_t i = 0; i < n; ++i) {
+        const double yi = z0 + b[0] * x[i];
+        z0 = 0. * x[i] - a[1] * yi;
+        y[i] = yi;
+    }
+    z[0] = z0;
+}
+
+/* effects.py:33-55 */
+void ko_low_pass_coefficients(double frequency, double b[1], double a[2])
+{
+    if (frequency == 0.) {
+        b[0] = 0.;
+        a[0] = 1.;
+        a[1] = -1.;
+        return;
+    }
+    if (isinf(frequency)) {
+        b[0] = 1.;
+        a[0] = 1.;
+        a[1] = 0.;
+        return;
+    }
+    a[0] = 1.;
+    a[1] = -exp(-KO_TAU * frequency / KO_SAMPLING_RATE);
+    b[0] = 1. - fabs(a[1]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* _filters.c:41-59 */
+int ko_ring_filter_init(ko_ring_filter *f, size_t length, double alpha)
+{
+    if (length == 0 || length > (size_t)60 * KO_SAMPLING_RATE)
+        return -1;
+    f->data = (double *)calloc(length, sizeof(double));
+    if (!f->data)
+        return -1;
+    f->length = length;
+    f->position = 0;
+    f->alpha = alpha;
+    return 0;
+}
+
+void ko_ring_filter_free(ko_ring_filter *f)
+{
+    free(f->data);
+    f->data = NULL;
+}
+
+/* _filters.c:231-254 (forward), :257-280 (backward), :283-306 (echo);
+ * peek :77-81, append :87-92. */
+void ko_ring_filter_run(ko_ring_filter *f, int kind, const double *x, size_t n, double *y)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const double old = f->data[f->position];
+        double store;
+        if (kind == KO_COMB_FORWARD) {
+            y[i] = x[i] + f->alpha * old;
+            store = x[i];
+        } else if (kind == KO_COMB_BACKWARD) {
+            y[i] = x[i] + f->alpha * old;
+            store = y[i];
+        } else {
+            y[i] = old;
+            store = f->alpha * y[i] + x[i];
+        }
+        f->data[f->position++] = store;
+        f->position %= f->length;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+static int ko_is_prime(int v)
+{
+    if (v < 2)
+        return 0;
+    for (int d = 2; (long)d * d <= v; ++d)
+        if (v % d == 0)
+            return 0;
+    return 1;
+}
+
+/* primes.py:124-141: next n primes >= start. */
+void ko_next_primes(int n, int start, int *out)
+{
+    int v = start;
+    for (int i = 0; i < n; ++i) {
+        while (!ko_is_prime(v))
+            ++v;
+        out[i] = v;
+        ++v;
+    }
+}
+
+/* effects.py:592-606 */
+double ko_reverb_alpha(double delay_time, double decay)
+{
+    if (decay <= 0.)
+        return 0.;
+    return exp(-KO_PI * delay_time / decay);
+}
+
+/* effects.py:575-590 */
+int ko_reverb_init(ko_reverb *r, double decay, double pre_delay, double dry_wet, int n_echos)
+{
+    int *taps = (int *)malloc(sizeof(int) * (size_t)n_echos);
+    r->n_echos = n_echos;
+    r->dry_wet = fmin(fmax(dry_wet, 0.), 1.);
+    r->filters = (ko_ring_filter *)calloc((size_t)n_echos, sizeof(ko_ring_filter));
+    ko_next_primes(n_echos, (int)(pre_delay * KO_SAMPLING_RATE), taps);
+    for (int k = 0; k < n_echos; ++k) {
+        const double alpha = ko_reverb_alpha((double)taps[k] / KO_SAMPLING_RATE, decay);
+        if (ko_ring_filter_init(&r->filters[k], (size_t)taps[k], alpha) != 0) {
+            free(taps);
+            return -1;
+        }
+    }
+    free(taps);
+    return 0;
+}
+
+void ko_reverb_free(ko_reverb *r)
+{
+    for (int k = 0; k < r->n_echos; ++k)
+        ko_ring_filter_free(&r->filters[k]);
+    free(r->filters);
+    r->filters = NULL;
+}
+
+/* effects.py:608-615: y = sum_k comb_k(x) (in tap order); y /= n;
+ * out = (1-dw)*x + dw*y  (math.py:68-75). */
+void ko_reverb_run(ko_reverb *r, const double *x, size_t n, double *out)
+{
+    double *y = (double *)malloc(sizeof(double) * n);
+    double *acc = (double *)malloc(sizeof(double) * n);
+    for (int k = 0; k < r->n_echos; ++k) {
+        ko_ring_filter_run(&r->filters[k], KO_COMB_BACKWARD, x, n, y);
+        if (k == 0)
+            memcpy(acc, y, sizeof(double) * n);
+        else
+            for (size_t i = 0; i < n; ++i)
+                acc[i] += y[i];
+    }
+    for (size_t i = 0; i < n; ++i) {
+        const double wet = acc[i] / (double)r->n_echos;
+        out[i] = (1. - r->dry_wet) * x[i] + r->dry_wet * wet;
+    }
+    free(y);
+    free(acc);
+}
+
+/* ------------------------------------------------------------------------ */
+/* mixer.py:41-49 */
+void ko_mixer(const double *inputs, const double *gains, int n, size_t len, double *out)
+{
+    for (size_t i = 0; i < len; ++i)
+        out[i] = 0.;
+    for (int c = 0; c < n; ++c)
+        for (size_t i = 0; i < len; ++i)
+            out[i] += gains[c] * inputs[(size_t)c * len + i];
+    if (n > 1)
+        for (size_t i = 0; i < len; ++i)
+            out[i] = out[i] / (double)n;
+}
+
+/* panning.py:27-31 */
+static double ko_pan_law_exponent(double pan_law, double center)
+{
+    return (pan_law - 20. * log10(2.)) / (2. * 20. * log10(center));
+}
+
+/* panning.py:35-81 */
+void ko_panning_amplitudes(double level, int mode, int has_pan_law, double pan_law,
+                           double lr[2])
+{
+    double left, right, alpha = 1.;
+    level = fmin(fmax(level, -1.), 1.);
+    const double angle = KO_TAU / 8 * (1. + level);
+    if (mode == 0) {
+        left = .5 * (1. - level);
+        right = .5 * (1. + level);
+    } else if (mode == 1) {
+        left = cos(angle);
+        right = sin(angle);
+    } else {
+        left = sqrt(.5 * (1. - level) * cos(angle));
+        right = sqrt(.5 * (1. + level) * sin(angle));
+    }
+    if (has_pan_law) {
+        if (mode == 0)
+            alpha = ko_pan_law_exponent(pan_law, .5);
+        else if (mode == 1)
+            alpha = ko_pan_law_exponent(pan_law, cos(KO_TAU / 8));
+        else
+            alpha = ko_pan_law_exponent(pan_law, sqrt(.5 * cos(KO_TAU / 8)));
+        left = pow(left, alpha);
+        right = pow(right, alpha);
+    }
+    lr[0] = left;
+    lr[1] = right;
+}
+
+/* mixer.py:95-104: sum += (gain * pan) * x per channel, / n if n > 1. */
+void ko_stereo_mixer(const double *inputs, const double *gains, const double *pan_lr, int n,
+                     size_t len, double *out)
+{
+    for (size_t i = 0; i < 2 * len; ++i)
+        out[i] = 0.;
+    for (int c = 0; c < n; ++c) {
+        const double gl = gains[c] * pan_lr[2 * c + 0];
+        const double gr = gains[c] * pan_lr[2 * c + 1];
+        for (size_t i = 0; i < len; ++i) {
+            out[i] += gl * inputs[(size_t)c * len + i];
+            out[len + i] += gr * inputs[(size_t)c * len + i];
+        }
+    }
+    if (n > 1)
+        for (size_t i = 0; i < 2 * len; ++i)
+            out[i] = out[i] / (double)n;
+}
+
+/* ------------------------------------------------------------------------ */
+/* One voice, one block: voices.py:55-74 (note handling + (amp*osc)*env),
+ * oscillators.py:130-133, envelopes.py:40-45, effects.py:371-385. */
+static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
+{
+    double phase[KO_BUFFER_SIZE], env[KO_BUFFER_SIZE];
+    if (bk->wave[v] == KO_WAVE_ONE) {
+        for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+            buf[i] = 1.;
+    } else {
+        ko_sample_phase_const(bk->frequency[v], bk->phase[v], phase, &bk->phase[v]);
+        ko_wave(bk->wave[v], phase, KO_BUFFER_SIZE, bk->duty[v], buf);
+    }
+    if (bk->has_env) {
+        ko_envelope_sample(&bk->env[v], KO_BUFFER_SIZE, env);
+        for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+            buf[i] = bk->amplitude[v] * buf[i] * env[i];
+    }
+    if (bk->has_filter) {
+        const double *c = bk->coef_table + 5 * (size_t)bk->coef_index[v];
+        const double b[3] = {c[0], c[1], c[2]};
+        const double a[3] = {1., c[3], c[4]};
+        double z[2] = {bk->z0[v], bk->z1[v]};
+        ko_lfilter2(b, a, buf, KO_BUFFER_SIZE, z, buf);
+        bk->z0[v] = z[0];
+        bk->z1[v] = z[1];
+    }
+}
+
+static void ko_apply_event(ko_bank *bk, const ko_event *ev)
+{
+    const int v = (int)ev->voice;
+    if (ev->kind == 2) {
+        bk->coef_index[v] = (int32_t)ev->index;
+        return;
+    }
+    if (bk->has_env)
+        ko_envelope_gate(&bk->env[v], ev->kind == 1);
+    if (ev->kind == 1) {
+        bk->amplitude[v] = ev->velocity;
+        bk->frequency[v] = ev->frequency;
+    }
+}
+
+static void ko_render_range(ko_bank *bk, int v0, int v1, int n_blocks, const ko_event *events,
+                            size_t n_events, double *bus, double *voices)
+{
+    const int ch = bk->stereo ? 2 : 1;
+    const size_t span = (size_t)n_blocks * KO_BUFFER_SIZE;
+    double buf[KO_BUFFER_SIZE];
+    size_t e = 0;
+    while (e < n_events && (int)events[e].voice < v0)
+        ++e;
+    for (int v = v0; v < v1; ++v) {
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            while (e < n_events && (int)events[e].voice == v && (int)events[e].block == blk)
+                ko_apply_event(bk, &events[e++]);
+            ko_voice_block(bk, v, buf);
+            if (voices)
+                memcpy(voices + (size_t)v * span + (size_t)blk * KO_BUFFER_SIZE, buf, sizeof(buf));
+            double *out = bus + (size_t)blk * ch * KO_BUFFER_SIZE;
+            if (bk->stereo) {
+                const double gl = bk->gain[v] * bk->pan_l[v];
+                const double gr = bk->gain[v] * bk->pan_r[v];
+                for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+                    out[i] += gl * buf[i];
+                    out[KO_BUFFER_SIZE + i] += gr * buf[i];
+                }
+            } else {
+                const double g = bk->gain[v];
+                for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                    out[i] += g * buf[i];
+            }
+        }
+        while (e < n_events && (int)events[e].voice == v)
+            ++e; /* events beyond the rendered span */
+    }
+}
+
+void ko_bank_render(ko_bank *bk, int n_blocks, const ko_event *events, size_t n_events,
+                    double *mix, double *voices, int n_threads)
+{
+    const int ch = bk->stereo ? 2 : 1;
+    const size_t bus_len = (size_t)n_blocks * ch * KO_BUFFER_SIZE;
+    memset(mix, 0, sizeof(double) * bus_len);
+    if (n_threads <= 1) {
+        ko_render_range(bk, 0, bk->n_voices, n_blocks, events, n_events, mix, voices);
+    } else {
+#ifdef _OPENMP
+        double *partial = (double *)calloc(bus_len * (size_t)n_threads, sizeof(double));
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+        for (int t = 0; t < n_threads; ++t) {
+            const int v0 = (int)((long)bk->n_voices * t / n_threads);
+            const int v1 = (int)((long)bk->n_voices * (t + 1) / n_threads);
+            ko_render_range(bk, v0, v1, n_blocks, events, n_events, partial + bus_len * (size_t)t,
+                            voices);
+        }
+        for (int t = 0; t < n_threads; ++t)
+            for (size_t i = 0; i < bus_len; ++i)
+                mix[i] += partial[bus_len * (size_t)t + i];
+        free(partial);
+#else
+        ko_render_range(bk, 0, bk->n_voices, n_blocks, events, n_events, mix, voices);
+#endif
+    }
+    if (bk->n_voices > 1)
+        for (size_t i = 0; i < bus_len; ++i)
+            mix[i] = mix[i] / (double)bk->n_voices;
+}
+
+int ko_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

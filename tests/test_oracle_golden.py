@@ -1,0 +1,391 @@
+"""Pin the CPU oracle against fixtures produced by the REAL reference
+(tools/gen_golden.py; numpy 2.2.6 / scipy 1.15.3 / reference C extensions) and
+against the known-answer tests of the reference's own test-suite.
+
+Bars: bit-exact (==) wherever the reference's arithmetic is IEEE basic ops
+(phase, non-sine waves, envelope, lfilter, ring filters, reverb, mixers); a
+stated ulp-level tolerance where a transcendental from a different libm is
+involved (np.sin vs glibc sin; scipy.signal.butter's zpk route vs the closed
+form)."""
+import numpy as np
+import pytest
+
+B = 256
+TAU = 2. * np.pi
+DT = 1. / 44100
+WAVES = ('sine', 'square', 'sawtooth', 'triangle')
+SIN_TOL = 4e-16      # np.sin (SIMD) vs glibc sin: <= 2 ulp at |y| <= 1
+BUTTER_RTOL = 4e-15  # closed form vs scipy zpk->tf
+
+
+def eq(a, b):
+    np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+# ---- sample_phase / waves -----------------------------------------------------
+def test_sample_phase_const_bit_exact(oracle, golden):
+    g = golden('phase_waves')
+    for i, f in enumerate(g['frequencies']):
+        for j, s in enumerate(g['starts']):
+            ph, nx = oracle.sample_phase(f, s)
+            eq(ph, g['phase'][i, j])
+            assert nx == g['next'][i, j]
+
+
+def test_sample_phase_array_bit_exact(oracle, golden):
+    g = golden('phase_waves')
+    freq = golden('inputs')['frequency_arrays']
+    cur = float(g['array_start'])
+    for b in range(3):
+        ph, cur = oracle.sample_phase(freq[b], cur)
+        eq(ph, g['array_phase'][b])
+        assert cur == g['array_next'][b]
+
+
+@pytest.mark.parametrize('name', WAVES)
+def test_waves(oracle, golden, name):
+    g = golden('phase_waves')
+    got = oracle.wave(name, g['phase'].ravel()).reshape(g['phase'].shape)
+    if name == 'sine':
+        np.testing.assert_allclose(got, g[name], rtol=0, atol=SIN_TOL)
+    else:
+        eq(got, g[name])
+
+
+def test_pwm_wave(oracle, golden):
+    g = golden('phase_waves')
+    eq(oracle.wave('pwm', g['phase'].ravel(), duty=.3).reshape(g['phase'].shape),
+       g['pwm_duty_0p3'])
+    osc = oracle.OscillatorState(441., 'pwm', duty=.3)
+    for b in range(4):
+        eq(osc.block(), g['pwm_441_0p3'][b])
+
+
+def test_phasor_and_lfo(oracle, golden):
+    g = golden('phase_waves')
+    cur = .25
+    for b in range(64):
+        assert cur == g['phasor_3p7_start_0p25'][b]
+        cur = oracle.phasor_step(3.7, cur)
+    s_scale, s_off, v_scale, v_off = g['lfo_scale_offset']
+    cur = 0.
+    for b in range(8):  # oscillators.py:173-181, scalar shape
+        got = s_scale * oracle.wave('sine', [cur])[0] + s_off
+        assert abs(got - g['lfo_scalar'][b]) <= 1e-12
+        cur = oracle.phasor_step(2., cur)
+    osc = oracle.OscillatorState(5., 'triangle')
+    for b in range(8):
+        eq(v_scale * osc.block() + v_off, g['lfo_vector'][b])
+
+
+@pytest.mark.parametrize('freq', [440, 19999])
+@pytest.mark.parametrize('name', WAVES)
+def test_oscillator_64_blocks(oracle, golden, name, freq):
+    g = golden('oscillator_blocks')
+    kept = list(g['kept_blocks'])
+    osc = oracle.OscillatorState(float(freq), name)
+    for b in range(64):
+        out = osc.block()
+        if b in kept:
+            want = g['%s_%d' % (name, freq)][kept.index(b)]
+            if name == 'sine':
+                np.testing.assert_allclose(out, want, rtol=0, atol=SIN_TOL)
+            else:
+                eq(out, want)
+    assert osc.phase == float(g['%s_%d_final_phase' % (name, freq)])
+
+
+def test_reference_oscillator_kats(oracle):
+    """tests/test_audio_oscillators.py:83-111 of the reference, restated."""
+    ph, _ = oracle.sample_phase(440., 1.234)
+    assert ph[0] == 1.234                               # :83-95 phase[0] == startPhase
+    t = DT * np.arange(B)
+    np.testing.assert_almost_equal(ph, np.mod(TAU * 440. * t + 1.234, TAU), 7)
+    _, nxt = oracle.sample_phase(1. / (DT * B), 0.)     # :107-111 f = 1/INTERVAL
+    assert nxt == 0.
+    ph, _ = oracle.sample_phase(4000., 0.)              # :97-105 wrap
+    assert ph.min() >= 0. and ph.max() < TAU
+    osc = oracle.OscillatorState(440., 'sine')          # :144-155
+    np.testing.assert_almost_equal(osc.block(), np.sin(TAU * 440. * t), 7)
+
+
+# ---- envelope -------------------------------------------------------------------
+ENV_CASES = ['adsr_default', 'adsr_regate', 'ar_loop_5s', 'ar_zero_attack', 'd_only', 'r_only',
+             'retrigger_on', 'retrigger_off', 'loop_gate_off', 'overshoot_clip_low',
+             'overshoot_large', 'double_events']
+
+
+@pytest.mark.parametrize('case', ENV_CASES)
+def test_envelope_bit_exact(oracle, golden, case):
+    g = golden('envelope')
+    a, d, s, r, over, retrig, loop = g[case + '_params']
+    env = oracle.OracleEnvelope(a, d, s, r, DT, over, bool(retrig), bool(loop))
+    script = {}
+    for blk, gate in g[case + '_script']:
+        script.setdefault(int(blk), []).append(bool(gate))
+    samples = []
+    for b in range(int(g[case + '_n_blocks'])):
+        for gate in script.get(b, ()):
+            env.gate(gate)
+        out = env.sample(B)
+        samples.append(out)
+        assert out[-1] == g[case + '_block_last'][b]
+        assert env.active == bool(g[case + '_active'][b])
+    eq(np.concatenate(samples)[::int(g[case + '_decim'])], g[case + '_samples'])
+
+
+def test_reference_envelope_kats(oracle):
+    """tests/test_audio__envelope.py:53-78 of the reference, restated."""
+    env = oracle.OracleEnvelope(1., 1., .5, 1., dt=.1)
+    assert env.sample(0).size == 0
+    eq(env.sample(10), np.zeros(10))                    # OFF -> zeros
+    env.gate(True)
+    assert env.sample(10)[-1] == 1.
+    assert env.sample(10)[-1] == .5
+    eq(env.sample(10), np.full(10, .5))
+    env.gate(False)
+    assert env.sample(10)[-1] == 0.
+    eq(env.sample(10), np.zeros(10))
+    assert not env.active
+
+
+# ---- Filter -----------------------------------------------------------------------
+def test_filter_grid_and_table(oracle, golden):
+    g = golden('filter')
+    grid = oracle.filter_grid()
+    # np.logspace = np.power(2, linspace): NumPy's SIMD pow vs glibc pow differ by
+    # <= 1 ulp on ~5% of the points; the end points (index clipping) are exact.
+    np.testing.assert_allclose(grid, g['grid'], rtol=2.3e-16, atol=0)
+    assert grid[0] == g['grid'][0] and grid[-1] == g['grid'][-1]
+    table = oracle.coefficient_table(g['grid'])
+    ref = g['table']                                    # [1000][b0 b1 b2 a0 a1 a2]
+    eq(ref[:, 3], np.ones(1000))
+    np.testing.assert_allclose(table[:, :3], ref[:, :3], rtol=BUTTER_RTOL, atol=0)
+    np.testing.assert_allclose(table[:, 3:], ref[:, 4:], rtol=BUTTER_RTOL, atol=1e-15)  # a1 crosses 0
+    for req, want in zip(g['index_requests'], g['index_results']):
+        assert oracle.filter_grid_index(g['grid'], req) == want
+
+
+@pytest.mark.parametrize('src', ['noise', 'saw'])
+def test_lfilter_bit_exact_with_reference_coefficients(oracle, golden, src):
+    g = golden('filter')
+    x = golden('inputs')['noise'][:8 * B] if src == 'noise' else g['saw_input']
+    for c in g['cutoffs']:
+        row = g['table'][oracle.filter_grid_index(g['grid'], c)]
+        z = np.zeros(2)
+        ys = []
+        for b in range(8):
+            y, z = oracle.lfilter2(row[:3], row[3:], x[b * B:(b + 1) * B], z)
+            ys.append(y)
+        eq(np.concatenate(ys), g['%s_%g' % (src, c)])
+        eq(z, g['%s_%g_state' % (src, c)])
+
+
+def test_filter_closed_form_coefficients_within_tolerance(oracle, golden):
+    """Whole Filter path with the oracle's own design: parity bound reported."""
+    g = golden('filter')
+    x = golden('inputs')['noise'][:8 * B]
+    table = oracle.coefficient_table()
+    worst = 0.
+    for c in g['cutoffs']:
+        row = table[oracle.filter_grid_index(oracle.filter_grid(), c)]
+        y, _ = oracle.lfilter2(row[:3], np.r_[1., row[3:]], x, np.zeros(2))
+        worst = max(worst, np.abs(y - g['noise_%g' % c]).max())
+    assert worst <= 1e-11
+
+
+def test_filter_sweep_and_stereo(oracle, golden):
+    g = golden('filter')
+    x = golden('inputs')['noise']
+    sched = {int(b): f for b, f in g['sweep_schedule']}
+    z = np.zeros(2)
+    ys = []
+    for b in range(8):
+        if b in sched:
+            row = g['table'][oracle.filter_grid_index(g['grid'], sched[b])]
+        y, z = oracle.lfilter2(row[:3], row[3:], x[b * B:(b + 1) * B], z)
+        ys.append(y)
+    eq(np.concatenate(ys), g['sweep_noise'])
+    row = g['table'][oracle.filter_grid_index(g['grid'], 1000.)]
+    for ch in range(2):
+        y, _ = oracle.lfilter2(row[:3], row[3:], x[ch * B:(ch + 1) * B], np.zeros(2))
+        eq(y, g['stereo_1000'][ch])
+
+
+def test_one_pole_and_tremolo(oracle, golden):
+    g = golden('filter')
+    for f, (b0, a1) in zip(g['one_pole_freqs'], g['one_pole_coeffs']):
+        b, a = oracle.low_pass_coefficients(f)
+        assert abs(b[0] - b0) <= 2e-16 and abs(a[1] - a1) <= 2e-16
+    # effects.py:117-133: PwmOscillator(3 Hz) -> one-pole lfilter -> AM
+    x = golden('inputs')['noise'][:8 * B]
+    depth, smooth, duty = .8, 1., .5
+    decay = max(1e-6, smooth * min(duty, 1. - duty))
+    b, a = oracle.low_pass_coefficients(1. / decay)
+    lfo = oracle.OscillatorState(3., 'pwm', duty=duty)
+    z = np.zeros(1)
+    out = []
+    for blk in range(8):
+        filt, z = oracle.lfilter1(b, a, lfo.block(), z)
+        env = (1. - depth) + depth * (.5 + .5 * filt)
+        out.append(env * x[blk * B:(blk + 1) * B])
+    np.testing.assert_allclose(np.concatenate(out), g['tremolo_noise'], rtol=0, atol=1e-15)
+
+
+# ---- ring filters ----------------------------------------------------------------
+@pytest.mark.parametrize('kind', ['forward', 'backward', 'echo'])
+def test_ring_filters_bit_exact(oracle, golden, kind):
+    g = golden('ring_filters')
+    x = golden('inputs')['noise']
+    for K in (1, 7, 234, 1327):
+        total = 1664 if K == 1327 else 640
+        for bs in (256, 123):
+            f = oracle.OracleRingFilter(kind, K, .9 if K != 7 else .5)
+            ys, pos = [], 0
+            while pos < total:
+                n = min(bs, total - pos)
+                ys.append(f.filter(x[pos:pos + n]))
+                pos += n
+            eq(np.concatenate(ys), g['%s_K%d_bs%d' % (kind, K, bs)])
+
+
+def test_reference_ring_filter_kats(oracle):
+    """tests/test_audio_filters.py:24-73 of the reference, restated: impulse,
+    K=234, alpha=.9, block 123."""
+    K, alpha, bs = 234, .9, 123
+    x = np.zeros(3 * K)
+    x[0] = 1.
+
+    def run(kind):
+        f = oracle.OracleRingFilter(kind, K, alpha)
+        return np.concatenate([f.filter(x[p:p + bs]) for p in range(0, x.size, bs)])
+
+    y = run('forward')
+    assert y[0] == 1. and y[K] == alpha and y[2 * K] == 0.
+    y = run('backward')
+    assert y[0] == 1. and y[K] == alpha and y[2 * K] == alpha * alpha
+    y = run('echo')
+    assert y[0] == 0. and y[K] == 1. and y[2 * K] == alpha
+
+
+# ---- reverb -----------------------------------------------------------------------
+def test_reverb(oracle, golden):
+    g = golden('reverb')
+    assert oracle.next_primes(10, int(.03 * 44100)) == list(g['taps_default'])
+    assert list(g['taps_default']) == [1327, 1361, 1367, 1373, 1381, 1399, 1409, 1423, 1427, 1429]
+    noise = golden('inputs')['noise']
+    impulse = np.zeros(24 * B)
+    impulse[0] = 1.
+    for pname, kw in (('default', {}), ('decay3', dict(decay=3., dry_wet=.7))):
+        alphas = [oracle.reverb_alpha(k / 44100, kw.get('decay', 1.5)) for k in g['taps_default']]
+        np.testing.assert_allclose(alphas, g[pname + '_alphas'], rtol=2e-16, atol=0)
+        for iname, x in (('impulse', impulse), ('noise', noise)):
+            r = oracle.OracleReverb(**kw)
+            out = np.concatenate([r.run(x[b * B:(b + 1) * B]) for b in range(24)])
+            np.testing.assert_allclose(out, g['%s_%s' % (pname, iname)], rtol=0, atol=1e-15)
+    r = oracle.OracleReverb(decay=.5, pre_delay=.001, dry_wet=1.5, n_echos=4)
+    assert [r.c.filters[k].length for k in range(4)] == list(g['short_taps'])
+    out = np.concatenate([r.run(noise[b * B:(b + 1) * B]) for b in range(6)])
+    np.testing.assert_allclose(out, g['short_noise'], rtol=0, atol=1e-15)
+
+
+# ---- mixers -------------------------------------------------------------------------
+def test_mixers(oracle, golden):
+    g = golden('mixer')
+    x = golden('inputs')['mixer_inputs']
+    for n in (1, 2, 3, 64):
+        eq(oracle.mixer(x[:n], g['gains'][:n]), g['mono_%d' % n])
+    got = oracle.stereo_mixer(x[:20], g['gains'][:20], g['stereo_20_pannings'])
+    np.testing.assert_allclose(got, g['stereo_20'], rtol=0, atol=2e-16)
+    for mode in ('linear', 'constant_power', 'mixture'):
+        for p, want, want_law in zip(g['pan_levels'], g['pan_' + mode],
+                                     g['pan_%s_law_m3' % mode]):
+            np.testing.assert_allclose(oracle.panning_amplitudes(p, mode), want, rtol=0,
+                                       atol=2e-16)
+            np.testing.assert_allclose(oracle.panning_amplitudes(p, mode, -3.), want_law, rtol=0,
+                                       atol=4e-16)
+
+
+# ---- chains -------------------------------------------------------------------------
+def _bank_from_patch(oracle, patch, table, grid):
+    bank = oracle.OracleBank(patch.n_voices, patch.has_env, patch.has_filter, patch.stereo)
+    bank.wave[:] = patch.wave
+    bank.frequency[:] = patch.frequency
+    bank.set_envelopes(patch.attack, patch.decay, patch.sustain, patch.release, patch.overshoot,
+                       patch.retrigger, patch.loop)
+    bank.coef_table = table
+    bank.coef_index[:] = [oracle.filter_grid_index(grid, c) for c in patch.cutoff]
+    bank.gain[:] = patch.gain
+    pan = np.array([oracle.panning_amplitudes(p) for p in patch.pan])
+    bank.pan_l[:], bank.pan_r[:] = pan[:, 0], pan[:, 1]
+    return bank
+
+
+def _ref_table(golden):
+    g = golden('filter')
+    return np.ascontiguousarray(g['table'][:, [0, 1, 2, 4, 5]]), g['grid']
+
+
+def test_single_voice_chain(oracle, golden):
+    from klang_amd import patches as P
+    g = golden('chains')
+    table, grid = _ref_table(golden)
+    bank = oracle.OracleBank(1, True, False, False)
+    bank.wave[:] = P.WAVE_SAWTOOTH
+    bank.set_envelope(0, .01, .05, .6, .04)
+    ev = np.concatenate([P.make_events(0, 0, P.EV_NOTE_ON, .8, 220.),
+                         P.make_events(0, 6, P.EV_NOTE_OFF, 0., 220.),
+                         P.make_events(0, 9, P.EV_NOTE_ON, .5, 329.6275569128699)])
+    mix, _ = bank.render(16, ev)
+    eq(mix[:, 0, :], g['voice_saw_adsr'])
+
+
+def test_config3_mini_bit_exact(oracle, golden):
+    from klang_amd import patches as P
+    g = golden('chains')
+    table, grid = _ref_table(golden)
+    patch = P.polyphonic_saw_patch(n_voices=48, n_blocks=40, off_base=6, off_span=12)
+    bank = _bank_from_patch(oracle, patch, table, grid)
+    mix, voices = bank.render(patch.n_blocks, patch.events, want_voices=True)
+    eq(mix[:, 0, :], g['config3_mini_mix'])
+    eq(bank.phase, g['config3_mini_final_phase'])
+    # threaded baseline path only re-associates the bus sum
+    bank2 = _bank_from_patch(oracle, patch, table, grid)
+    mix2, _ = bank2.render(patch.n_blocks, patch.events, n_threads=4)
+    np.testing.assert_allclose(mix2, mix, rtol=0, atol=1e-15)
+
+
+def test_config2_haunting_patch(oracle, golden):
+    from klang_amd import patches as P
+    g = golden('chains')
+    table, grid = _ref_table(golden)
+    patch = P.haunting_patch()
+    bank = _bank_from_patch(oracle, patch, table, grid)
+    mix, _ = bank.render(2048, patch.events)
+    # sine (libm vs NumPy SIMD) and cos/sin pan amplitudes: ulp-level, not bit-exact
+    np.testing.assert_allclose(mix[g['config2_kept_blocks']], g['config2_mix'], rtol=0, atol=1e-15)
+
+
+def test_config4_mini_reverb_chain(oracle, golden):
+    from klang_amd import patches as P
+    g = golden('chains')
+    patch = P.reverb_patch(n_channels=6, n_blocks=72, period=24, note_blocks=5)
+    table, grid = _ref_table(golden)
+    bank = _bank_from_patch(oracle, patch, table, grid)
+    _, voices = bank.render(patch.n_blocks, patch.events, want_voices=True)
+    wet = np.empty_like(voices)
+    for v in range(patch.n_voices):
+        rv = oracle.OracleReverb(**patch.reverb)
+        for b in range(patch.n_blocks):
+            wet[v, b * B:(b + 1) * B] = rv.run(voices[v, b * B:(b + 1) * B])
+    mix = np.array([oracle.mixer(wet[:, b * B:(b + 1) * B], patch.gain)
+                    for b in range(patch.n_blocks)])
+    np.testing.assert_allclose(mix[g['config4_kept_blocks']], g['config4_mini_mix'], rtol=0,
+                               atol=1e-14)
+
+
+def test_hello_world_blocks(oracle, golden):
+    g = golden('hello_world')
+    osc = oracle.OscillatorState(440., 'sine')
+    for b in range(4):
+        eq(osc.block().astype(np.float32), g['first_blocks_f32'][b])

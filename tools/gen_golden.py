@@ -1,0 +1,396 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (container only).
+
+The reference (atheler/klang at /root/reference) is imported through
+tools/ref_loader.py with its two C extensions compiled into oracle/_ref/ by
+oracle/Makefile.  Outputs are data only: seeded inputs and the reference's
+outputs (float64).  No reference source is copied.  Where /root/reference is
+absent this script does nothing.
+
+Run:  make -C oracle && python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_loader  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+B = 256
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.))
+
+
+def main():
+    if not ref_loader.reference_available():
+        print('reference tree absent: nothing generated')
+        return 0
+    ref_loader.load_reference()
+    import scipy
+    import klang.audio as A
+    from klang.audio import oscillators as OSC, waves as W, effects as FX
+    from klang.audio.filters import ForwardCombFilter, BackwardCombFilter, EchoFilter
+    from klang.audio.mixer import Mixer, StereoMixer
+    from klang.audio.panning import panning_amplitudes
+    from klang.audio._envelope import Envelope as CEnvelope
+    from klang.execution import determine_execution_order
+    from klang.messages import Note
+    from klang.primes import find_next_primes
+    from klang_amd import patches as P
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    meta = np.array(['numpy ' + np.__version__, 'scipy ' + scipy.__version__,
+                     'reference atheler/klang v0.2.1 C extensions: gcc -O2'])
+
+    # ---- shared inputs ---------------------------------------------------
+    rng = np.random.default_rng(0)
+    noise = 2. * rng.random(24 * B) - 1.
+    mix_in = 2. * np.random.default_rng(1).random((64, B)) - 1.
+    freq_arr = 200. + 100. * np.random.default_rng(2).random((3, B))
+    save('inputs', meta=meta, noise=noise, mixer_inputs=mix_in, frequency_arrays=freq_arr)
+
+    # ---- sample_phase + waves (oscillators.py:41-67, waves.py) -----------
+    freqs = np.array([0.5, 55., 440., 4186.01, 19999.])
+    starts = np.array([0., 1.234])
+    phase = np.empty((len(freqs), len(starts), B))
+    nxt = np.empty((len(freqs), len(starts)))
+    wav = {k: np.empty_like(phase) for k in ('sine', 'square', 'sawtooth', 'triangle')}
+    pwm = np.empty_like(phase)
+    for i, f in enumerate(freqs):
+        for j, s in enumerate(starts):
+            ph, nx = OSC.sample_phase(f, s)
+            phase[i, j], nxt[i, j] = ph, nx
+            for k in wav:
+                wav[k][i, j] = W.WAVE_FUNCTIONS[k](ph)
+            pwm[i, j] = 2. * (ph < A.oscillators.TAU * .3) - 1.
+    # array-frequency branch: three chained blocks
+    arr_phase = np.empty((3, B))
+    arr_next = np.empty(3)
+    cur = .5
+    for b in range(3):
+        arr_phase[b], cur = OSC.sample_phase(freq_arr[b], cur)
+        arr_next[b] = cur
+    # scalar Phasor stepping (oscillators.py:91-96)
+    ph = OSC.Phasor(frequency=3.7, startPhase=.25)
+    phasor = []
+    for _ in range(64):
+        ph.update()
+        phasor.append(ph.output.value)
+    # PwmOscillator block (oscillators.py:237-267)
+    pw = OSC.PwmOscillator(frequency=441., dutyCycle=.3)
+    pwm_blocks = []
+    for _ in range(4):
+        pw.update()
+        pwm_blocks.append(pw.output.value)
+    # Lfo, scalar and vector shapes (oscillators.py:143-190)
+    lfo_s = OSC.Lfo(frequency=2., shape=1, outputRange=(100., 1000.))
+    lfo_v = OSC.Lfo(frequency=5., wave_func=W.triangle, shape=B, outputRange=(-2., 3.))
+    lfo_scalar, lfo_vector = [], []
+    for _ in range(8):
+        lfo_s.update()
+        lfo_v.update()
+        lfo_scalar.append(lfo_s.output.value)
+        lfo_vector.append(lfo_v.output.value)
+    save('phase_waves', frequencies=freqs, starts=starts, phase=phase, next=nxt, pwm_duty_0p3=pwm,
+         array_phase=arr_phase, array_next=arr_next, array_start=np.array(.5),
+         phasor_3p7_start_0p25=np.array(phasor), pwm_441_0p3=np.array(pwm_blocks),
+         lfo_scalar=np.array(lfo_scalar), lfo_vector=np.array(lfo_vector),
+         lfo_scale_offset=np.array([lfo_s.scale, lfo_s.offset, lfo_v.scale, lfo_v.offset]),
+         **wav)
+
+    # ---- Oscillator over 64 blocks (oscillators.py:111-140) --------------
+    out = {}
+    for f in (440., 19999.):
+        for k in ('sine', 'square', 'sawtooth', 'triangle'):
+            osc = OSC.Oscillator(frequency=f, wave_func=W.WAVE_FUNCTIONS[k])
+            blocks = []
+            for b in range(64):
+                osc.update()
+                if b < 12 or b >= 60:
+                    blocks.append(osc.output.value)
+            out['%s_%d' % (k, f)] = np.array(blocks)
+            out['%s_%d_final_phase' % (k, f)] = np.array(osc.currentPhase)
+    save('oscillator_blocks', kept_blocks=np.array(list(range(12)) + [60, 61, 62, 63]), **out)
+
+    # ---- C Envelope (_envelope.c) ----------------------------------------
+    DT = 1. / 44100
+    env_out = {}
+
+    def run_env(name, params, script, n_blocks, decim, **kw):
+        """script: {block: [gate bools]}.  Stores decimated samples + per-block
+        (stage-as-active, value) snapshots + the full first 2 blocks."""
+        env = CEnvelope(*params, DT, **kw)
+        samples, last, active = [], [], []
+        for b in range(n_blocks):
+            for g in script.get(b, ()):
+                env.gate(g)
+            s = env.sample(B)
+            samples.append(s)
+            last.append(s[-1])
+            active.append(env.active)
+        s = np.concatenate(samples)
+        env_out[name + '_params'] = np.array(list(params) + [kw.get('overshoot', 1e-3),
+                                                              float(kw.get('retrigger', False)),
+                                                              float(kw.get('loop', False))])
+        env_out[name + '_script'] = np.array([(b, int(g)) for b in sorted(script)
+                                               for g in script[b]]).reshape(-1, 2)
+        env_out[name + '_decim'] = np.array(decim)
+        env_out[name + '_samples'] = s[::decim]
+        env_out[name + '_block_last'] = np.array(last)
+        env_out[name + '_active'] = np.array(active)
+        env_out[name + '_n_blocks'] = np.array(n_blocks)
+
+    run_env('adsr_default', (.1, .2, .8, 1.), {0: [True], 60: [False]}, 260, 8)
+    run_env('adsr_regate', (.01, .1, .7, .5), {0: [True], 10: [False], 14: [True], 30: [False]},
+            64, 1)
+    run_env('ar_loop_5s', (.1, 0., 1., 4.9), {0: [True]}, 900, 32, loop=True)
+    run_env('ar_zero_attack', (0., 0., 1., .05), {0: [True], 4: [False]}, 16, 1)
+    run_env('d_only', (0., .05, 0., .05), {0: [True]}, 16, 1)
+    run_env('r_only', (0., 0., 1., 1.), {0: [True], 2: [False]}, 180, 8)
+    run_env('retrigger_on', (.05, .1, .5, .2), {0: [True], 3: [True], 20: [False]}, 48, 1,
+            retrigger=True)
+    run_env('retrigger_off', (.05, .1, .5, .2), {0: [True], 3: [True], 20: [False]}, 48, 1,
+            retrigger=False)
+    run_env('loop_gate_off', (.01, .02, .6, .03), {0: [True], 8: [False]}, 24, 1, loop=True)
+    run_env('overshoot_clip_low', (.02, .05, .5, .1), {0: [True], 10: [False]}, 32, 1,
+            overshoot=0.)
+    run_env('overshoot_large', (.02, .05, .5, .1), {0: [True], 10: [False]}, 32, 1,
+            overshoot=5.)
+    run_env('double_events', (.02, .05, .5, .1), {0: [True, False, True], 6: [False, True],
+                                                  12: [False]}, 24, 1)
+    save('envelope', **env_out)
+
+    # ---- Filter (effects.py:239-385) -------------------------------------
+    fil = FX.Filter()
+    fc = fil.filters[0].coefficients
+    table = np.array([np.concatenate([b, a]) for b, a in fc.coefficients])
+    fout = dict(grid=fc.frequencies, table=table)
+    saw_osc = OSC.Oscillator(frequency=110., wave_func=W.sawtooth)
+    saw = []
+    for _ in range(8):
+        saw_osc.update()
+        saw.append(saw_osc.output.value)
+    saw = np.concatenate(saw)
+    fout['saw_input'] = saw
+    cutoffs = [20., 440., 2000., 20000., 5., 30000.]
+    fout['cutoffs'] = np.array(cutoffs)
+    for name, x in (('noise', noise[:8 * B]), ('saw', saw)):
+        for c in cutoffs:
+            f = FX.Filter(frequency=c)
+            ys = []
+            for b in range(8):
+                f.input.set_value(x[b * B:(b + 1) * B])
+                f.update()
+                ys.append(f.output.value)
+            fout['%s_%g' % (name, c)] = np.concatenate(ys)
+            fout['%s_%g_state' % (name, c)] = np.array(f.filters[0].state)
+    # cutoff change mid-stream (state kept, effects.py:301-303)
+    f = FX.Filter(frequency=300.)
+    ys = []
+    sched = {0: 300., 3: 5000., 5: 80., 6: 80.}
+    for b in range(8):
+        if b in sched:
+            f.frequency.set_value(sched[b])
+        f.input.set_value(noise[b * B:(b + 1) * B])
+        f.update()
+        ys.append(f.output.value)
+    fout['sweep_schedule'] = np.array(sorted(sched.items()))
+    fout['sweep_noise'] = np.concatenate(ys)
+    # stereo input path (effects.py:379-383)
+    f = FX.Filter(frequency=1000.)
+    st = np.stack([noise[:B], noise[B:2 * B]])
+    f.input.set_value(st)
+    f.update()
+    fout['stereo_1000'] = f.output.value
+    # requested frequency -> grid index for a handful of requests
+    req = np.array([5., 20., 20.0000001, 100., 440., 1999.9, 2000., 2013.877, 8000., 19999.,
+                    20000., 20001., 30000.])
+    fout['index_requests'] = req
+    fout['index_results'] = np.array([int(np.searchsorted(fc.frequencies, r).clip(0, 999))
+                                      for r in req])
+    # one-pole (effects.py:33-55) + its lfilter use in Tremolo (effects.py:117-133)
+    lp = np.array([5., 50., 1. / 1e-6, 1. / .5])
+    fout['one_pole_freqs'] = lp
+    fout['one_pole_coeffs'] = np.array([[FX.low_pass_coefficients(v)[0][0],
+                                         FX.low_pass_coefficients(v)[1][1]] for v in lp])
+    trem = FX.Tremolo(rate=3., depth=.8, smoothness=1., dutyCycle=.5)
+    ys = []
+    for b in range(8):
+        trem.input.set_value(noise[b * B:(b + 1) * B])
+        trem.update()
+        ys.append(trem.output.value)
+    fout['tremolo_noise'] = np.concatenate(ys)
+    save('filter', **fout)
+
+    # ---- ring filters (_filters.c) ----------------------------------------
+    rout = {}
+    kinds = (('forward', ForwardCombFilter), ('backward', BackwardCombFilter),
+             ('echo', EchoFilter))
+    for kname, cls in kinds:
+        for K in (1, 7, 234, 1327):
+            total = 1664 if K == 1327 else 640
+            for bs in (256, 123):
+                f = cls(K, .9 if K != 7 else .5)
+                ys = []
+                pos = 0
+                while pos < total:
+                    n = min(bs, total - pos)
+                    ys.append(f.filter(noise[pos:pos + n]))
+                    pos += n
+                rout['%s_K%d_bs%d' % (kname, K, bs)] = np.concatenate(ys)
+    save('ring_filters', **rout)
+
+    # ---- Reverb (effects.py:564-615) ---------------------------------------
+    vout = dict(taps_default=np.array(find_next_primes(10, int(.03 * 44100))))
+    impulse = np.zeros(24 * B)
+    impulse[0] = 1.
+    for pname, kw in (('default', {}), ('decay3', dict(decay=3., dryWet=.7))):
+        for iname, x in (('impulse', impulse), ('noise', noise)):
+            r = FX.Reverb(**kw)
+            ys = []
+            for b in range(24):
+                r.input.set_value(x[b * B:(b + 1) * B])
+                r.update()
+                ys.append(r.output.value)
+            vout['%s_%s' % (pname, iname)] = np.concatenate(ys)
+        vout['%s_alphas' % pname] = np.array([f.alpha for f in FX.Reverb(**kw).filters])
+    r = FX.Reverb(decay=.5, preDelay=.001, dryWet=1.5, nEchos=4)  # short taps < block, clip
+    vout['short_taps'] = np.array([f.length for f in r.filters])
+    ys = []
+    for b in range(6):
+        r.input.set_value(noise[b * B:(b + 1) * B])
+        r.update()
+        ys.append(r.output.value)
+    vout['short_noise'] = np.concatenate(ys)
+    save('reverb', **vout)
+
+    # ---- Mixer / StereoMixer (mixer.py) ------------------------------------
+    mout = {}
+
+    from klang.block import Block as RefBlock
+
+    class Src(RefBlock):
+        def __init__(self, value):
+            super().__init__(nOutputs=1)
+            self.output.set_value(value)
+
+    gains = .25 + 1.5 * np.random.default_rng(3).random(64)
+    mout['gains'] = gains
+    for n in (1, 2, 3, 64):
+        m = Mixer()
+        for c in range(n):
+            m += Src(mix_in[c])
+            m.gains[-1] = gains[c]
+        m.update()
+        mout['mono_%d' % n] = m.output.value
+    hp = P.haunting_patch()
+    sm = StereoMixer()
+    for c in range(20):
+        sm += Src(mix_in[c])
+        sm.pannings[-1] = hp.pan[c]
+        sm.gains[-1] = gains[c]
+    sm.update()
+    mout['stereo_20'] = sm.output.value
+    mout['stereo_20_pannings'] = hp.pan[:20]
+    pans = np.array([-1., -.5, 0., .3, 1., 1.7])
+    mout['pan_levels'] = pans
+    for mode in ('linear', 'constant_power', 'mixture'):
+        mout['pan_%s' % mode] = np.array([panning_amplitudes(p, mode).ravel() for p in pans])
+        mout['pan_%s_law_m3' % mode] = np.array([panning_amplitudes(p, mode, -3.).ravel()
+                                                  for p in pans])
+    save('mixer', **mout)
+
+    # ---- Voice + chains (voices.py) and config mini-patches ----------------
+    cout = {}
+
+    def run_graph(top, n_blocks, hooks=None, keep=None):
+        order = determine_execution_order([top])
+        outs = []
+        for b in range(n_blocks):
+            if hooks and b in hooks:
+                for h in hooks[b]:
+                    h()
+            for blk in order:
+                blk.update()
+            if keep is None or b in keep:
+                outs.append(np.array(top.output.value, dtype=float))
+        return np.array(outs)
+
+    # single Voice: saw under ADSR, note on @0, off @6, on again @9 (new pitch)
+    voice = A.Voice(OSC.Oscillator(wave_func=W.sawtooth), A.ADSR(.01, .05, .6, .04))
+    hooks = {0: [lambda: voice.input.push(Note(57, .8, frequency=220.))],
+             6: [lambda: voice.input.push(Note(57, 0., frequency=220.))],
+             9: [lambda: voice.input.push(Note(64, .5, frequency=329.6275569128699))]}
+    cout['voice_saw_adsr'] = run_graph(voice, 16, hooks)
+
+    # config 3 mini: N voices saw -> ADSR -> Filter -> Mixer
+    p3 = P.polyphonic_saw_patch(n_voices=48, n_blocks=40, off_base=6, off_span=12)
+    mixer = Mixer()
+    voices3 = []
+    for v in range(p3.n_voices):
+        vc = A.Voice(OSC.Oscillator(wave_func=W.sawtooth),
+                     A.ADSR(p3.attack[v], p3.decay[v], p3.sustain[v], p3.release[v]))
+        fl = FX.Filter(frequency=p3.cutoff[v])
+        vc | fl
+        mixer += fl
+        voices3.append(vc)
+    hooks = {}
+    for ev in p3.events:
+        note = Note(0, float(ev['velocity']) if ev['kind'] == 1 else 0.,
+                    frequency=float(ev['frequency']))
+        hooks.setdefault(int(ev['block']), []).append(
+            lambda vc=voices3[int(ev['voice'])], note=note: vc.input.push(note))
+    cout['config3_mini_mix'] = run_graph(mixer, p3.n_blocks, hooks)
+    cout['config3_mini_final_phase'] = np.array([vc.oscillator.currentPhase for vc in voices3])
+    cout['config3_mini_voice0_last'] = np.array(voices3[0].output.value)
+
+    # config 2: the reference's own example patch, decimated (every 64th block)
+    import importlib
+    haunting = importlib.import_module('examples.haunting_envelopes')
+    keep = set(range(0, 2048, 64)) | {1, 2, 3, 2047}
+    cout['config2_kept_blocks'] = np.array(sorted(keep))
+    cout['config2_mix'] = run_graph(haunting.mixer, 2048, keep=keep)
+
+    # config 4 mini: per channel Voice(sine, AR(.01, 1.)) -> Reverb(3., .7) -> Mixer
+    p4 = P.reverb_patch(n_channels=6, n_blocks=72, period=24, note_blocks=5)
+    mixer4 = Mixer()
+    voices4 = []
+    for v in range(p4.n_voices):
+        vc = A.Voice(OSC.Oscillator(), A.AR(.01, 1.))
+        rv = FX.Reverb(decay=3., dryWet=.7)
+        vc | rv
+        mixer4 += rv
+        voices4.append(vc)
+    hooks = {}
+    for ev in p4.events:
+        note = Note(0, float(ev['velocity']) if ev['kind'] == 1 else 0.,
+                    frequency=float(ev['frequency']))
+        hooks.setdefault(int(ev['block']), []).append(
+            lambda vc=voices4[int(ev['voice'])], note=note: vc.input.push(note))
+    keep4 = set(range(0, 72, 3)) | {1, 71}
+    cout['config4_kept_blocks'] = np.array(sorted(keep4))
+    cout['config4_mini_mix'] = run_graph(mixer4, p4.n_blocks, hooks, keep=keep4)
+    save('chains', **cout)
+
+    # ---- hello_world (config 1): Oscillator(440) | Dac, pre-normalisation ---
+    osc = OSC.Oscillator(frequency=440.)
+    blocks = []
+    for b in range(4):
+        osc.update()
+        blocks.append(osc.output.value.astype(np.float32))
+    save('hello_world', first_blocks_f32=np.array(blocks), n_frames_1s=np.array(172 * B))
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
