@@ -1,0 +1,250 @@
+/*
+ * klang_mi.h -- C-ABI of libklang_mi.so, the MI355X (gfx950) evaluator for
+ * klang's per-block DSP hot path.
+ *
+ * The reference (atheler/klang) has no FFI registry; its own native swap point
+ * is the pair of CPython extension types klang.audio._envelope.Envelope and
+ * klang.audio._filters.{Forward,Backward}CombFilter/EchoFilter, selected by
+ * try/except import (klang/audio/envelopes.py:4-9, klang/audio/filters.py:19-31,
+ * 100-108), and the Block.update() protocol (klang/block.py:159-238).  This
+ * header is the batched restatement of that seam: every entry point cites the
+ * reference interface it replaces.  INTEGRATION.md shows the ctypes stubs a
+ * klang maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative klmi_status otherwise;
+ *     klmi_last_error() returns a thread-local message for the last failure.
+ *   - one klmi_ctx == one GPU (one process per GPU; shard voices across
+ *     processes and reduce the mix bus with RCCL, see klang_amd/sharding.py).
+ *   - the caller owns host buffers; the library owns device memory.  Pointers
+ *     named dev_* are device pointers the caller owns (e.g. a torch tensor).
+ *   - not re-entrant per ctx (the reference is single-threaded per graph);
+ *     callable from any host thread (each call sets the device).
+ *   - HIP only.  There is no CPU backend and no fallback: without a GPU
+ *     klmi_ctx_create fails with KLMI_E_DEVICE.
+ *   - all arithmetic is float64 in the reference's operation order (phase,
+ *     envelope and IIR recurrences are bit-identical to the reference's
+ *     float64 results); mix/voice outputs are rounded to float32 once.
+ */
+#ifndef KLANG_MI_H
+#define KLANG_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KLMI_BUFFER_SIZE 256      /* klang/config.py:5  BUFFER_SIZE */
+#define KLMI_SAMPLING_RATE 44100  /* klang/config.py:11 SAMPLING_RATE */
+#define KLMI_GRID_POINTS 1000     /* klang/audio/effects.py:260-265 */
+
+typedef enum {
+    KLMI_OK = 0,
+    KLMI_E_ARG = -1,     /* bad argument (ValueError in the reference's ext types) */
+    KLMI_E_DEVICE = -2,  /* HIP runtime error / no GPU */
+    KLMI_E_MEMORY = -3,  /* allocation failure (RuntimeError in _filters.c:124-136) */
+    KLMI_E_STATE = -4    /* call not valid in the object's current state */
+} klmi_status;
+
+/* Wave functions: klang/audio/waves.py:22-39, PwmOscillator oscillators.py:256-260. */
+typedef enum {
+    KLMI_WAVE_SINE = 0,
+    KLMI_WAVE_SQUARE = 1,
+    KLMI_WAVE_SAWTOOTH = 2,
+    KLMI_WAVE_TRIANGLE = 3,
+    KLMI_WAVE_PWM = 4,
+    KLMI_WAVE_ONE = 5,      /* no oscillator: constant 1.0 (bare envelope blocks) */
+    KLMI_WAVE_EXTERNAL = 6  /* samples supplied with klmi_bank_set_input (Filter/Reverb
+                               blocks fed by something outside the bank) */
+} klmi_wave;
+
+/* Envelope stages: klang/audio/_envelope.c:59-65. */
+typedef enum {
+    KLMI_STAGE_OFF = 0,
+    KLMI_STAGE_ATTACKING = 1,
+    KLMI_STAGE_DECAYING = 2,
+    KLMI_STAGE_SUSTAINING = 3,
+    KLMI_STAGE_RELEASING = 4
+} klmi_stage;
+
+/* Per-voice parameter / state fields for klmi_bank_set_params / _state_get / _state_set.
+ * All travel as float64 (integers and flags converted). */
+typedef enum {
+    /* parameters */
+    KLMI_F_FREQUENCY = 0,   /* Phasor.frequency in Hz (oscillators.py:81-89) */
+    KLMI_F_AMPLITUDE = 1,   /* Voice.amplitude (voices.py:41,60) */
+    KLMI_F_WAVE = 2,        /* klmi_wave */
+    KLMI_F_DUTY = 3,        /* PwmOscillator.dutyCycle (oscillators.py:245-254) */
+    KLMI_F_ATTACK = 4,      /* seconds; _envelope.c:220-237 (negative -> KLMI_E_ARG) */
+    KLMI_F_DECAY = 5,       /* _envelope.c:255-272 */
+    KLMI_F_SUSTAIN = 6,     /* [0,1]; _envelope.c:290-307 */
+    KLMI_F_RELEASE = 7,     /* _envelope.c:325-342 */
+    KLMI_F_OVERSHOOT = 8,   /* clipped to [1e-9,1e9]; _envelope.c:360-377 */
+    KLMI_F_LOOP = 9,        /* _envelope.c:173-179 */
+    KLMI_F_RETRIGGER = 10,  /* _envelope.c:166-172 */
+    KLMI_F_CUTOFF = 11,     /* Filter.frequency in Hz, quantised to the 1000-point grid
+                               (effects.py:271-274, 365-369) */
+    KLMI_F_GAIN = 12,       /* Mixer.gains[i] (mixer.py:33,43-44) */
+    KLMI_F_PAN = 13,        /* StereoMixer.pannings[i] (mixer.py:88,97-99) */
+    /* state */
+    KLMI_F_PHASE = 32,        /* Phasor.currentPhase (oscillators.py:89) */
+    KLMI_F_ENV_VALUE = 33,    /* _envelope.c:147 */
+    KLMI_F_ENV_STAGE = 34,    /* _envelope.c:146 (klmi_stage) */
+    KLMI_F_ENV_ENABLED = 35,  /* _envelope.c:148 */
+    KLMI_F_Z0 = 36,           /* _Filter.state[0] (effects.py:305-316) */
+    KLMI_F_Z1 = 37            /* _Filter.state[1] */
+} klmi_field;
+
+/* What one bank evaluates per voice, in the reference's terms:
+ *   osc = Oscillator(wave_func)                     oscillators.py:111-140
+ *   x   = has_env ? (amplitude*osc)*ADSR/AR/D/R     voices.py:66-74, envelopes.py:18-114
+ *   x   = has_filter ? Filter(x)                    effects.py:342-385
+ *   x   = has_reverb ? Reverb(x)                    effects.py:564-615
+ *   bus = stereo ? StereoMixer : Mixer over voices  mixer.py:15-104
+ */
+typedef struct {
+    int32_t has_env;
+    int32_t has_filter;
+    int32_t has_reverb;
+    int32_t stereo;
+    int32_t pan_mode;     /* 0 linear, 1 constant_power, 2 mixture (panning.py:57-65) */
+    int32_t has_pan_law;  /* panning.py:67-76 */
+    double pan_law;       /* dB, <= 0 */
+    double reverb_decay;      /* effects.py:575 decay (s) */
+    double reverb_pre_delay;  /* preDelay (s) */
+    double reverb_dry_wet;    /* dryWet, clipped to [0,1] (effects.py:586) */
+    int32_t reverb_n_echos;   /* nEchos > 0 */
+    int32_t reserved;
+} klmi_chain_desc;
+
+/* Block-boundary events, the batched form of Voice.process_incoming_notes
+ * (voices.py:55-64) and of Input.set_value on frequency inputs. */
+typedef enum {
+    KLMI_EV_NOTE_OFF = 0,    /* envelope.gate(False)                                */
+    KLMI_EV_NOTE_ON = 1,     /* gate(True); amplitude = velocity; frequency = note  */
+    KLMI_EV_SET_CUTOFF = 2,  /* Filter.frequency.set_value(frequency)               */
+    KLMI_EV_SET_FREQUENCY = 3 /* Oscillator.frequency.set_value(frequency)           */
+} klmi_event_kind;
+
+typedef struct {
+    uint32_t voice;
+    uint32_t block;   /* block index relative to the next klmi_bank_render call */
+    uint32_t kind;    /* klmi_event_kind */
+    uint32_t reserved;
+    double velocity;  /* NOTE_ON */
+    double frequency; /* NOTE_ON, SET_CUTOFF, SET_FREQUENCY (Hz) */
+} klmi_event;
+
+typedef struct klmi_ctx klmi_ctx;
+typedef struct klmi_bank klmi_bank;
+typedef struct klmi_env klmi_env;
+typedef struct klmi_comb klmi_comb;
+
+const char *klmi_last_error(void);
+const char *klmi_version(void);
+
+/* ---- context ------------------------------------------------------------ */
+/* One GPU.  `stream` is a hipStream_t the launches are ordered on (e.g.
+ * torch.cuda.current_stream().cuda_stream) or NULL for a library-owned one. */
+int klmi_ctx_create(int device, void *stream, klmi_ctx **out);
+int klmi_ctx_destroy(klmi_ctx *ctx);
+int klmi_ctx_synchronize(klmi_ctx *ctx);
+
+/* Host-side design helpers (no GPU work).
+ * effects.py:260-269: the 1000-point log2 grid and scipy.signal.butter(N=2,
+ * 'lowpass', Wn) per grid point; b/a as scipy returns them (a[0] == 1). */
+int klmi_filter_grid(double *freqs /* [KLMI_GRID_POINTS] */);
+int klmi_filter_grid_index(double frequency);  /* effects.py:271-274; returns the row */
+int klmi_butter2_lowpass(double wn, double b[3], double a[3]);
+/* _envelope.c:112-119, 187-198: {attackCoef, attackBase, decayCoef, decayBase,
+ * releaseCoef, releaseBase}. */
+int klmi_envelope_coefficients(double attack, double decay, double sustain, double release,
+                               double dt, double overshoot, double out[6]);
+/* panning.py:35-81 */
+int klmi_panning_amplitudes(double level, int mode, int has_pan_law, double pan_law,
+                            double lr[2]);
+/* primes.py:133-141 and effects.py:587-606: tap lengths and comb gains of a Reverb. */
+int klmi_reverb_design(double decay, double pre_delay, int n_echos, int32_t *taps,
+                       double *alphas);
+
+/* ---- voice bank: the hot path -------------------------------------------- */
+/* Replaces N x {Oscillator.update, EnvelopeBase.update, Voice.update,
+ * Filter.update, Reverb.update} + Mixer.update per 256-sample buffer
+ * (klang/klang.py:76-78 hot loop). */
+int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_desc *desc, klmi_bank **out);
+int klmi_bank_destroy(klmi_bank *bank);
+
+int klmi_bank_set_params(klmi_bank *bank, int field, int first, int count, const double *host);
+int klmi_bank_state_get(klmi_bank *bank, int field, int first, int count, double *host);
+int klmi_bank_state_set(klmi_bank *bank, int field, int first, int count, const double *host);
+
+/* Queue events for the next render (any order; applied per voice in block
+ * order, same-block events in submission order).  Events whose block lies
+ * beyond the next render stay queued, re-based. */
+int klmi_bank_events(klmi_bank *bank, const klmi_event *events, size_t n);
+
+/* Mixer divisor: mixer.py:46-47 divides the bus by nInputs when nInputs > 1.
+ * Default is that rule on this bank's n_voices; a sharded patch sets 1.0 on
+ * every shard and divides by the global voice count after the reduce. */
+int klmi_bank_set_mix_divisor(klmi_bank *bank, double divisor);
+
+/* External input for KLMI_WAVE_EXTERNAL voices: x[n_voices][n_blocks*256]
+ * float64.  Renders consume it block by block (several renders may walk through
+ * one input); previews read from the current position without consuming. */
+int klmi_bank_set_input(klmi_bank *bank, const double *host_x, int n_blocks);
+
+/* THE hot call.  Renders n_blocks buffers of every voice, advances all state,
+ * consumes due events, writes the mix bus [n_blocks][channels][256] float32
+ * (channels = stereo ? 2 : 1).  _device writes to a device pointer and does
+ * not synchronise. */
+int klmi_bank_render(klmi_bank *bank, int n_blocks, float *host_mix);
+int klmi_bank_render_device(klmi_bank *bank, int n_blocks, float *dev_mix);
+
+/* Materialise per-voice streams (Output.value of the fused chain's last block
+ * for voices [first, first+count)): out[count][n_blocks*256].  A *preview*:
+ * state and the event queue are left untouched, so the next klmi_bank_render
+ * of the same span mixes exactly these samples.  _f64 returns the unrounded
+ * float64 values (parity diagnostics). */
+int klmi_bank_render_voices(klmi_bank *bank, int first, int count, int n_blocks, float *host_out);
+int klmi_bank_render_voices_f64(klmi_bank *bank, int first, int count, int n_blocks,
+                                double *host_out);
+int klmi_bank_render_voices_device(klmi_bank *bank, int first, int count, int n_blocks,
+                                   float *dev_out);
+
+/* Reverb delay-line state of one voice: rings concatenated in tap order
+ * (sum of tap lengths float64) and the ring positions [n_echos]. */
+int klmi_bank_reverb_state_get(klmi_bank *bank, int voice, double *rings, int32_t *positions);
+
+/* Kernel timing of the last render call, measured with HIP events on the
+ * ctx stream: milliseconds spent in the voice kernel(s) and launches made. */
+int klmi_bank_last_kernel_ms(klmi_bank *bank, float *voice_ms, int *launches);
+
+/* ---- envelope batch: klang.audio._envelope.Envelope, x count --------------- */
+/* _envelope.c:518-535 (ctor; overshoot clipped), :549-567 gate, :636-663
+ * sample(n) -> float64[count][n], :385-393 active.  count == 1 is the ext type. */
+int klmi_env_create(klmi_ctx *ctx, int count, double attack, double decay, double sustain,
+                    double release, double dt, double overshoot, int retrigger, int loop,
+                    klmi_env **out);
+int klmi_env_destroy(klmi_env *env);
+int klmi_env_set(klmi_env *env, int field, int first, int count, const double *host);
+int klmi_env_get(klmi_env *env, int field, int first, int count, double *host);
+int klmi_env_gate(klmi_env *env, int first, int count, int on);
+int klmi_env_sample(klmi_env *env, long n, double *host_out);
+int klmi_env_active(klmi_env *env, int32_t *host_out /* [count] */);
+
+/* ---- ring-buffer filter batch: klang.audio._filters.*, x count ------------- */
+/* _filters.c:113-139 ctor (length int, alpha=.9; length > 60*44100 fails),
+ * :231-306 filter(x) for kind 0 forward comb, 1 backward comb, 2 echo.
+ * x, y: float64[count][n]. */
+int klmi_comb_create(klmi_ctx *ctx, int kind, int count, int length, double alpha,
+                     klmi_comb **out);
+int klmi_comb_destroy(klmi_comb *comb);
+int klmi_comb_set_alpha(klmi_comb *comb, int first, int count, const double *host);
+int klmi_comb_filter(klmi_comb *comb, const double *host_x, long n, double *host_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

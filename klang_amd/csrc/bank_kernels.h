@@ -1,0 +1,317 @@
+// bank_kernels.h -- the fused voice kernel (oscillator -> envelope -> biquad ->
+// mix / materialise) and its deterministic bus reduction, for gfx950.
+//
+// Mapping: one lane = one voice; phase, envelope stage/value and the IIR
+// z-state live in VGPRs for the whole launch and touch HBM once per launch.
+// SoA device arrays, voice index fastest => every load/store is a coalesced
+// 64-lane access.  The mix-down goes through a wave-private LDS tile
+// [CHUNK samples][64 voices] that is read back transposed (lane = sample), so
+// the cross-voice sum costs one ds_write_b32 per sample and 1/4 ds_read_b128
+// + one add per sample instead of a 6-step cross-lane reduction per sample.
+#pragma once
+#include "dsp_device.h"
+#include <type_traits>
+
+namespace klmi {
+
+__constant__ double c_time[kBlock + 1];  // t[n] = DT * n  (helpers.py:27-32)
+
+struct BankView {
+    int n;  // voices in the bank
+    // parameters
+    const double *duty;
+    const int32_t *wave;
+    const double *env_coef;    // [7][n]: aCoef aBase dCoef dBase rCoef rBase sustain
+    const uint32_t *env_flags; // bit0 loop, bit1 retrigger
+    const double *coef_table;  // [rows][5]: b0 b1 b2 a1 a2
+    const double *gain_l, *gain_r;  // gain (mono) or gain*pan_l / gain*pan_r (stereo)
+    // state
+    double *phase, *env_value, *z0, *z1;
+    uint32_t *env_state;       // bits 0-2 stage, bit 8 enabled
+    // frequency / amplitude are state too once NOTE_ON events have been applied
+    double *frequency_rw, *amplitude_rw;
+    int32_t *coef_index_rw;
+    // events of this render call, sorted by (voice, block); CSR by voice
+    const uint32_t *ev_offset;  // [n+1]
+    const uint32_t *ev_block, *ev_kind;
+    const int32_t *ev_index;    // SET_CUTOFF: table row
+    const double *ev_velocity, *ev_frequency;
+    uint32_t *ev_cursor;        // [n] progress through the voice's events
+    // external input [span][n] (time-major) for W_EXTERNAL voices
+    const double *ext_input;
+};
+
+enum OutMode : int {
+    OUT_MIX_MONO = 0,    // partial bus per workgroup
+    OUT_MIX_STEREO = 1,
+    OUT_VOICES_F32 = 2,  // out[voice][span] float32
+    OUT_VOICES_F64 = 3,  // out[voice][span] float64
+    OUT_BUS_F64 = 4      // out[sample][voice] float64 (input of the reverb kernel)
+};
+
+template <int MODE> struct TileTraits;
+template <> struct TileTraits<OUT_MIX_MONO> { using T = float; static constexpr int chunk = 64, stride = 68, planes = 1; };
+template <> struct TileTraits<OUT_MIX_STEREO> { using T = float; static constexpr int chunk = 32, stride = 68, planes = 2; };
+template <> struct TileTraits<OUT_VOICES_F32> { using T = float; static constexpr int chunk = 64, stride = 65, planes = 1; };
+template <> struct TileTraits<OUT_VOICES_F64> { using T = double; static constexpr int chunk = 32, stride = 65, planes = 1; };
+template <> struct TileTraits<OUT_BUS_F64> { using T = double; static constexpr int chunk = 64, stride = 1, planes = 0; };
+
+constexpr int kWavesPerGroup = 4;
+constexpr int kGroup = 64 * kWavesPerGroup;
+
+// Sum of one tile row (64 voices) read as 16 x ds_read_b128, pairwise order.
+__device__ __forceinline__ float row_sum64(const float *row)
+{
+    const float4 *r4 = reinterpret_cast<const float4 *>(row);
+    float s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 v = r4[j];
+        s[j] = (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int j = 0; j < w; ++j)
+            s[j] = s[j] + s[j + w];
+    return s[0];
+}
+
+// grid.x = ceil(count / 256) workgroups of 4 waves.
+// partial: [gridDim.x][n_blocks*planes*256] float32 (mix modes)
+// out:     voices / bus buffer (other modes)
+template <bool ENV, bool FILT, int MODE>
+__global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, int count,
+                                                       int block_base,      // first block, relative to this call
+                                                       uint32_t clock_base,  // absolute number of block_base (events)
+                                                       int n_blocks,
+                                                       int span_total,  // samples per voice row in `out`
+                                                       float *__restrict__ partial,
+                                                       void *__restrict__ out)
+{
+    using TT = TileTraits<MODE>;
+    using T = typename TT::T;
+    constexpr int CH = TT::chunk;
+    constexpr int NCHUNK = kBlock / CH;
+    constexpr int PLANES = TT::planes;
+    constexpr bool MIX = (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
+
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // wave-private tile(s): [PLANES][CH][stride]
+    T *tile = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (PLANES ? PLANES : 1) * CH * TT::stride;
+    // cross-wave combine area (mix modes): [waves][PLANES][CH] floats after the tiles
+    float *xwave = reinterpret_cast<float *>(
+        smem_raw + sizeof(T) * (size_t)kWavesPerGroup * (PLANES ? PLANES : 1) * CH * TT::stride);
+
+    const int local = blockIdx.x * kGroup + threadIdx.x;
+    const bool live = local < count;
+    const int v = first + (live ? local : 0);
+
+    // ---- load parameters and state ------------------------------------------------
+    double freq = bk.frequency_rw[v];
+    double amp = bk.amplitude_rw[v];
+    const int wave_id = bk.wave[v];
+    const double duty_edge = kTau * bk.duty[v];  // oscillators.py:259
+    // wave function shared by the whole wavefront, or -1
+    const int first_wave = __builtin_amdgcn_readfirstlane(wave_id);
+    const int uniform_wave = __all(wave_id == first_wave) ? first_wave : -1;
+    double phase = bk.phase[v];
+
+    EnvParams ep;
+    EnvState es;
+    if (ENV) {
+        ep.aCoef = bk.env_coef[0 * (size_t)bk.n + v];
+        ep.aBase = bk.env_coef[1 * (size_t)bk.n + v];
+        ep.dCoef = bk.env_coef[2 * (size_t)bk.n + v];
+        ep.dBase = bk.env_coef[3 * (size_t)bk.n + v];
+        ep.rCoef = bk.env_coef[4 * (size_t)bk.n + v];
+        ep.rBase = bk.env_coef[5 * (size_t)bk.n + v];
+        ep.sustain = bk.env_coef[6 * (size_t)bk.n + v];
+        const uint32_t fl = bk.env_flags[v];
+        ep.loop = fl & 1u;
+        ep.retrigger = fl & 2u;
+        const uint32_t st = bk.env_state[v];
+        es.stage = (int)(st & 7u);
+        es.enabled = (st >> 8) & 1u;
+        es.value = bk.env_value[v];
+        es.select(ep);
+    }
+
+    Biquad bq;
+    int coef_row = 0;
+    if (FILT) {
+        coef_row = bk.coef_index_rw[v];
+        const double *c = bk.coef_table + 5 * (size_t)coef_row;
+        bq.b0 = c[0], bq.b1 = c[1], bq.b2 = c[2], bq.a1 = c[3], bq.a2 = c[4];
+        bq.z0 = bk.z0[v];
+        bq.z1 = bk.z1[v];
+    }
+
+    double gl = 0., gr = 0.;
+    if (MIX) {
+        gl = live ? bk.gain_l[v] : 0.;
+        if (MODE == OUT_MIX_STEREO)
+            gr = live ? bk.gain_r[v] : 0.;
+    }
+
+    // ---- event cursor -------------------------------------------------------------
+    uint32_t ev_i = bk.ev_offset[v] + bk.ev_cursor[v];
+    const uint32_t ev_end = bk.ev_offset[v + 1];
+    uint32_t next_ev = (live && ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
+
+    for (int b = 0; b < n_blocks; ++b) {
+        const uint32_t abs_block = clock_base + (uint32_t)b;
+        // voices.py:55-64: notes are consumed at the block boundary
+        while (next_ev <= abs_block) {
+            const uint32_t kind = bk.ev_kind[ev_i];
+            if (kind == 1u) {
+                if (ENV)
+                    es.gate(ep, true);
+                amp = bk.ev_velocity[ev_i];
+                freq = bk.ev_frequency[ev_i];
+            } else if (kind == 0u) {
+                if (ENV)
+                    es.gate(ep, false);
+            } else if (kind == 2u) {
+                if (FILT) {
+                    coef_row = bk.ev_index[ev_i];
+                    const double *c = bk.coef_table + 5 * (size_t)coef_row;
+                    bq.b0 = c[0], bq.b1 = c[1], bq.b2 = c[2], bq.a1 = c[3], bq.a2 = c[4];
+                }
+            } else {
+                freq = bk.ev_frequency[ev_i];
+            }
+            ++ev_i;
+            next_ev = (ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
+        }
+
+        const double omega = kTau * freq;  // oscillators.py:60  (TAU * frequency) * t
+        const double start = phase;
+
+        for (int c = 0; c < NCHUNK; ++c) {
+            const int s0 = b * kBlock + c * CH;  // sample offset inside this launch
+            // One chunk of CH samples.  WK is the wave function when the whole
+            // wavefront agrees on it (compile-time dispatch), or -1 (per-lane switch).
+            auto run_chunk = [&](auto wk) {
+                constexpr int WK = decltype(wk)::value;
+#pragma unroll 8
+                for (int i = 0; i < CH; ++i) {
+                    const int n = c * CH + i;
+                    const int wsel = (WK >= 0) ? WK : wave_id;
+                    double x;
+                    if (wsel == W_EXTERNAL) {
+                        x = bk.ext_input[(size_t)(block_base * kBlock + s0 + i) * bk.n + v];
+                    } else if (wsel == W_ONE) {
+                        x = 1.;
+                    } else {
+                        const double p = np_mod_tau(omega * c_time[n] + start);
+                        x = wave_eval(wsel, p, duty_edge);
+                    }
+                    if (ENV) {
+                        const double e = es.step(ep);
+                        x = amp * x * e;  // voices.py:73  (amplitude * osc) * env
+                    }
+                    if (FILT)
+                        x = bq.step(x);
+
+                    if constexpr (MODE == OUT_MIX_MONO) {
+                        tile[i * TT::stride + lane] = (float)(gl * x);
+                    } else if constexpr (MODE == OUT_MIX_STEREO) {
+                        tile[i * TT::stride + lane] = (float)(gl * x);
+                        tile[(CH + i) * TT::stride + lane] = (float)(gr * x);
+                    } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
+                        tile[i * TT::stride + lane] = (T)x;
+                    } else {
+                        if (live)
+                            reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
+                    }
+                }
+            };
+            switch (uniform_wave) {
+            case W_SINE: run_chunk(std::integral_constant<int, W_SINE>{}); break;
+            case W_SQUARE: run_chunk(std::integral_constant<int, W_SQUARE>{}); break;
+            case W_SAWTOOTH: run_chunk(std::integral_constant<int, W_SAWTOOTH>{}); break;
+            case W_TRIANGLE: run_chunk(std::integral_constant<int, W_TRIANGLE>{}); break;
+            case W_PWM: run_chunk(std::integral_constant<int, W_PWM>{}); break;
+            default: run_chunk(std::integral_constant<int, -1>{}); break;
+            }
+            // the tile is wave-private: LDS operations of one wave execute in order;
+            // the fence only stops the compiler from moving them across this point
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            if constexpr (MIX) {
+                // lane = sample: sum the 64 voices of this wave, then the 4 waves
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    for (int r = lane; r < CH; r += 64) {
+                        xwave[(wave * PLANES + pl) * CH + r] =
+                            row_sum64(tile + (size_t)(pl * CH + r) * TT::stride);
+                    }
+                }
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < PLANES * CH; idx += kGroup) {
+                    const int pl = idx / CH, r = idx % CH;
+                    float acc = xwave[(0 * PLANES + pl) * CH + r];
+#pragma unroll
+                    for (int w = 1; w < kWavesPerGroup; ++w)
+                        acc += xwave[(w * PLANES + pl) * CH + r];
+                    // partial layout per group: [block][plane][256]
+                    const size_t o = ((size_t)b * PLANES + pl) * kBlock + c * CH + r;
+                    partial[(size_t)blockIdx.x * n_blocks * PLANES * kBlock + o] = acc;
+                }
+                __syncthreads();
+            } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
+                // lane = sample: write 64 voice rows, CH contiguous samples each
+                T *o = reinterpret_cast<T *>(out);
+                const int base_local = blockIdx.x * kGroup + wave * 64;
+                for (int j = 0; j < 64; ++j) {
+                    if (base_local + j < count) {
+                        for (int r = lane; r < CH; r += 64)
+                            o[(size_t)(base_local + j) * span_total + s0 + r] =
+                                tile[r * TT::stride + j];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // oscillators.py:66-67: next start phase is sample 256 of this block
+        if (wave_id != W_EXTERNAL && wave_id != W_ONE)
+            phase = np_mod_tau(omega * c_time[kBlock] + start);
+    }
+
+    // ---- store state ----------------------------------------------------------------
+    if (live) {
+        bk.phase[v] = phase;
+        bk.frequency_rw[v] = freq;
+        bk.amplitude_rw[v] = amp;
+        if (ENV) {
+            bk.env_value[v] = es.value;
+            bk.env_state[v] = (uint32_t)es.stage | (es.enabled ? 0x100u : 0u);
+        }
+        if (FILT) {
+            bk.z0[v] = bq.z0;
+            bk.z1[v] = bq.z1;
+            bk.coef_index_rw[v] = coef_row;
+        }
+        bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
+    }
+}
+
+// bus[s] = (sum over workgroups, fixed order, float64) / divisor -> float32.
+__global__ void bus_reduce_kernel(const float *__restrict__ partial, int n_groups, size_t bus_len,
+                                  double divisor, float *__restrict__ bus)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bus_len)
+        return;
+    double acc = 0.;
+    for (int g = 0; g < n_groups; ++g)
+        acc += (double)partial[(size_t)g * bus_len + s];
+    bus[s] = (float)(acc / divisor);
+}
+
+}  // namespace klmi

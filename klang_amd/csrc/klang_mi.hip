@@ -1,0 +1,1576 @@
+// klang_mi.hip -- host side of libklang_mi.so: the C-ABI declared in
+// include/klang_mi.h over the gfx950 kernels in bank_kernels.h / aux_kernels.h /
+// reverb_kernels.h.  HIP only; no CPU fallback.
+#include "../../include/klang_mi.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.h"
+#include "bank_kernels.h"
+#include "reverb_kernels.h"
+
+using namespace klmi;
+
+// ---------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(KLMI_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                              \
+    } while (0)
+
+#define TRY(expr)          \
+    do {                   \
+        int rc_ = (expr);  \
+        if (rc_ != 0)      \
+            return rc_;    \
+    } while (0)
+
+extern "C" const char *klmi_last_error(void) { return g_error.c_str(); }
+extern "C" const char *klmi_version(void) { return "klang_mi 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------
+// host-side design helpers
+// ---------------------------------------------------------------------------------
+namespace {
+
+const double kSampleRate = KLMI_SAMPLING_RATE;
+
+// effects.py:260-265: np.logspace(log2(20), log2(20000), 1000, base=2)
+void make_grid(double *freqs)
+{
+    const double start = std::log2(20.), stop = std::log2(20000.);
+    const double step = (stop - start) / (double)(KLMI_GRID_POINTS - 1);
+    for (int i = 0; i < KLMI_GRID_POINTS; ++i) {
+        double y = (double)i * step + start;
+        if (i == KLMI_GRID_POINTS - 1)
+            y = stop;
+        freqs[i] = std::pow(2., y);
+    }
+}
+
+// scipy.signal.butter(2, wn, 'lowpass') (effects.py:266-269): Butterworth
+// prototype, pre-warp, bilinear transform, in closed form.
+void butter2(double wn, double b[3], double a[3])
+{
+    const double K = std::tan(kPi * wn / 2.);
+    const double K2 = K * K, r2 = std::sqrt(2.);
+    const double norm = 1. / (1. + r2 * K + K2);
+    b[0] = K2 * norm;
+    b[1] = 2. * b[0];
+    b[2] = b[0];
+    a[0] = 1.;
+    a[1] = 2. * (K2 - 1.) * norm;
+    a[2] = (1. - r2 * K + K2) * norm;
+}
+
+// effects.py:271-274: searchsorted (left) + clip
+int grid_index(const double *freqs, double f)
+{
+    const double *p = std::lower_bound(freqs, freqs + KLMI_GRID_POINTS, f);
+    return (int)std::min<ptrdiff_t>(p - freqs, KLMI_GRID_POINTS - 1);
+}
+
+// _envelope.c:112-119
+double env_coefficient(double rate, double overshoot)
+{
+    if (rate <= 0.)
+        return 0.;
+    return std::exp(-std::log((1.0 + overshoot) / overshoot) / rate);
+}
+
+// _envelope.c:187-198
+void env_coefficients(double attack, double decay, double sustain, double release, double dt,
+                      double overshoot, double out[6])
+{
+    out[0] = env_coefficient(attack / dt, overshoot);
+    out[1] = (1. + overshoot) * (1. - out[0]);
+    out[2] = env_coefficient(decay / dt, overshoot);
+    out[3] = (sustain - overshoot) * (1. - out[2]);
+    out[4] = env_coefficient(release / dt, overshoot);
+    out[5] = (0. - overshoot) * (1. - out[4]);
+}
+
+double clip(double v, double lo, double hi) { return std::fmin(std::fmax(v, lo), hi); }
+
+double pan_law_exponent(double law, double center)  // panning.py:27-31
+{
+    return (law - 20. * std::log10(2.)) / (2. * 20. * std::log10(center));
+}
+
+void panning(double level, int mode, int has_law, double law, double lr[2])  // panning.py:35-81
+{
+    level = clip(level, -1., 1.);
+    const double angle = kTau / 8 * (1. + level);
+    double l, r;
+    if (mode == 0) {
+        l = .5 * (1. - level);
+        r = .5 * (1. + level);
+    } else if (mode == 1) {
+        l = std::cos(angle);
+        r = std::sin(angle);
+    } else {
+        l = std::sqrt(.5 * (1. - level) * std::cos(angle));
+        r = std::sqrt(.5 * (1. + level) * std::sin(angle));
+    }
+    if (has_law) {
+        const double center = mode == 0 ? .5 : mode == 1 ? std::cos(kTau / 8)
+                                                         : std::sqrt(.5 * std::cos(kTau / 8));
+        const double alpha = pan_law_exponent(law, center);
+        l = std::pow(l, alpha);
+        r = std::pow(r, alpha);
+    }
+    lr[0] = l;
+    lr[1] = r;
+}
+
+bool is_prime(int v)
+{
+    if (v < 2)
+        return false;
+    for (int d = 2; (long)d * d <= v; ++d)
+        if (v % d == 0)
+            return false;
+    return true;
+}
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        if (count == 0)
+            count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess)
+            n = count;
+        return e;
+    }
+    hipError_t reserve(size_t count)
+    {
+        return count <= n ? hipSuccess : alloc(count);
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------
+struct klmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int live_objects = 0;            // banks / batches created on this context
+    std::vector<double> grid;        // 1000 frequencies
+    std::vector<double> table;       // [1000][5] b0 b1 b2 a1 a2
+    DevBuf<double> d_table;
+};
+
+static int use(klmi_ctx *ctx)
+{
+    if (!ctx)
+        return fail(KLMI_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
+{
+    if (!out)
+        return fail(KLMI_E_ARG, "klmi_ctx_create: out is null");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(KLMI_E_DEVICE, "klmi_ctx_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= n_dev)
+        return fail(KLMI_E_ARG, "klmi_ctx_create: device %d out of range (0..%d)", device, n_dev - 1);
+    HIP_TRY(hipSetDevice(device));
+    klmi_ctx *ctx = new klmi_ctx;
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(KLMI_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        ctx->own_stream = true;
+    }
+    ctx->grid.resize(KLMI_GRID_POINTS);
+    make_grid(ctx->grid.data());
+    ctx->table.resize((size_t)KLMI_GRID_POINTS * 5);
+    for (int i = 0; i < KLMI_GRID_POINTS; ++i) {
+        double b[3], a[3];
+        butter2(ctx->grid[i] / (KLMI_SAMPLING_RATE / 2), b, a);  // helpers.py:15 NYQUIST (int)
+        double *row = &ctx->table[(size_t)i * 5];
+        row[0] = b[0], row[1] = b[1], row[2] = b[2], row[3] = a[1], row[4] = a[2];
+    }
+    double t[kBlock + 1];
+    for (int n = 0; n <= kBlock; ++n)
+        t[n] = kDt * (double)n;  // helpers.py:30  dt * np.arange(length)
+    hipError_t e = ctx->d_table.alloc(ctx->table.size());
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_table.p, ctx->table.data(), ctx->table.size() * sizeof(double),
+                      hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof t);
+    if (e != hipSuccess) {
+        if (ctx->own_stream)
+            (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(KLMI_E_DEVICE, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int klmi_ctx_destroy(klmi_ctx *ctx)
+{
+    if (!ctx)
+        return 0;
+    if (ctx->live_objects != 0)
+        return fail(KLMI_E_STATE, "klmi_ctx_destroy: %d object(s) created on this context are "
+                                  "still alive; destroy them first", ctx->live_objects);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int klmi_ctx_synchronize(klmi_ctx *ctx)
+{
+    TRY(use(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int klmi_filter_grid(double *freqs)
+{
+    if (!freqs)
+        return fail(KLMI_E_ARG, "klmi_filter_grid: null output");
+    make_grid(freqs);
+    return 0;
+}
+
+extern "C" int klmi_filter_grid_index(double frequency)
+{
+    static std::vector<double> grid;
+    if (grid.empty()) {
+        std::vector<double> g(KLMI_GRID_POINTS);
+        make_grid(g.data());
+        grid.swap(g);
+    }
+    return grid_index(grid.data(), frequency);
+}
+
+extern "C" int klmi_butter2_lowpass(double wn, double b[3], double a[3])
+{
+    if (!(wn > 0. && wn < 1.))
+        return fail(KLMI_E_ARG, "klmi_butter2_lowpass: Wn must lie in (0, 1), got %g", wn);
+    butter2(wn, b, a);
+    return 0;
+}
+
+extern "C" int klmi_envelope_coefficients(double attack, double decay, double sustain,
+                                          double release, double dt, double overshoot,
+                                          double out[6])
+{
+    if (attack < 0 || decay < 0 || release < 0 || !(sustain >= 0. && sustain <= 1.) || !(dt > 0))
+        return fail(KLMI_E_ARG, "klmi_envelope_coefficients: invalid envelope parameters");
+    env_coefficients(attack, decay, sustain, release, dt, clip(overshoot, 1e-9, 1e9), out);
+    return 0;
+}
+
+extern "C" int klmi_panning_amplitudes(double level, int mode, int has_pan_law, double pan_law,
+                                       double lr[2])
+{
+    if (mode < 0 || mode > 2)
+        return fail(KLMI_E_ARG, "Invalid panning mode %d!", mode);  // panning.py:49-50
+    if (has_pan_law && pan_law > 0)
+        return fail(KLMI_E_ARG, "Pan law has to be negative!");      // panning.py:51-52
+    panning(level, mode, has_pan_law, pan_law, lr);
+    return 0;
+}
+
+extern "C" int klmi_reverb_design(double decay, double pre_delay, int n_echos, int32_t *taps,
+                                  double *alphas)
+{
+    if (n_echos <= 0)
+        return fail(KLMI_E_ARG, "klmi_reverb_design: nEchos must be > 0");  // effects.py:584
+    int v = (int)(pre_delay * kSampleRate);  // effects.py:589
+    if (v < 1)
+        v = 1;                               // primes.py:133 default start
+    for (int k = 0; k < n_echos; ++k) {
+        while (!is_prime(v))
+            ++v;
+        taps[k] = v;
+        // effects.py:592-606 compute_alpha(k / SAMPLING_RATE, decay)
+        alphas[k] = decay <= 0. ? 0. : std::exp(-kPi * ((double)v / kSampleRate) / decay);
+        ++v;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// voice bank
+// ---------------------------------------------------------------------------------
+struct klmi_bank {
+    klmi_ctx *ctx = nullptr;
+    int n = 0;
+    klmi_chain_desc desc{};
+    double mix_divisor = 1.;
+
+    // host shadows of the parameters the device arrays are derived from
+    std::vector<double> attack, decay, sustain, release, overshoot, gain, pan;
+    std::vector<uint8_t> loop, retrigger;
+
+    // device parameters
+    DevBuf<double> duty, env_coef, gain_l, gain_r;
+    DevBuf<int32_t> wave;
+    DevBuf<uint32_t> env_flags;
+    // device state: one slab so that a preview can snapshot/restore it with two copies
+    //   f64: phase | env_value | z0 | z1 | frequency | amplitude     (6n)
+    //   u32: env_state | coef_index | ev_cursor                       (3n)
+    DevBuf<double> state_f64, backup_f64;
+    DevBuf<uint32_t> state_u32, backup_u32;
+
+    // events: kept with absolute block numbers (block_clock at submission + relative
+    // block), uploaded sorted by (voice, block) when the queue changed; the device
+    // cursor per voice persists across render calls
+    std::vector<klmi_event> pending;
+    bool events_dirty = false;
+    uint32_t block_clock = 0;  // blocks rendered so far
+    DevBuf<uint32_t> ev_offset, ev_block, ev_kind;
+    DevBuf<int32_t> ev_index;
+    DevBuf<double> ev_velocity, ev_frequency;
+
+    // scratch
+    DevBuf<float> partial, dev_mix, dev_voices_f32;
+    DevBuf<double> dev_voices_f64, ext_input, bus_f64;
+    int ext_blocks = 0;   // blocks supplied by klmi_bank_set_input
+    int ext_cursor = 0;   // blocks of it consumed by renders so far
+
+    // reverb (has_reverb)
+    ReverbState reverb;
+    std::vector<int32_t> taps;
+    std::vector<double> alphas;
+    DevBuf<double> rings, d_alphas;
+    DevBuf<int32_t> d_taps, d_ring_offset;
+    std::vector<int32_t> ring_pos;  // host-tracked, identical for every voice
+    DevBuf<float> rv_partial;
+
+    // timing
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int timed_launches = 0;
+
+    double *f64(int slot) { return state_f64.p + (size_t)slot * n; }
+    uint32_t *u32(int slot) { return state_u32.p + (size_t)slot * n; }
+};
+
+enum { SL_PHASE = 0, SL_ENV_VALUE, SL_Z0, SL_Z1, SL_FREQ, SL_AMP, SL_F64_COUNT };
+enum { SL_ENV_STATE = 0, SL_COEF_INDEX, SL_EV_CURSOR, SL_U32_COUNT };
+
+static BankView make_view(klmi_bank *b)
+{
+    BankView v{};
+    v.n = b->n;
+    v.duty = b->duty.p;
+    v.wave = b->wave.p;
+    v.env_coef = b->env_coef.p;
+    v.env_flags = b->env_flags.p;
+    v.coef_table = b->ctx->d_table.p;
+    v.gain_l = b->gain_l.p;
+    v.gain_r = b->gain_r.p;
+    v.phase = b->f64(SL_PHASE);
+    v.env_value = b->f64(SL_ENV_VALUE);
+    v.z0 = b->f64(SL_Z0);
+    v.z1 = b->f64(SL_Z1);
+    v.frequency_rw = b->f64(SL_FREQ);
+    v.amplitude_rw = b->f64(SL_AMP);
+    v.env_state = b->u32(SL_ENV_STATE);
+    v.coef_index_rw = reinterpret_cast<int32_t *>(b->u32(SL_COEF_INDEX));
+    v.ev_cursor = b->u32(SL_EV_CURSOR);
+    v.ev_offset = b->ev_offset.p;
+    v.ev_block = b->ev_block.p;
+    v.ev_kind = b->ev_kind.p;
+    v.ev_index = b->ev_index.p;
+    v.ev_velocity = b->ev_velocity.p;
+    v.ev_frequency = b->ev_frequency.p;
+    v.ext_input = b->ext_input.p ? b->ext_input.p + (size_t)b->ext_cursor * kBlock * b->n : nullptr;
+    return v;
+}
+
+static int upload_env(klmi_bank *b, int first, int count)
+{
+    std::vector<double> coef((size_t)7 * count);
+    std::vector<uint32_t> flags(count);
+    for (int i = 0; i < count; ++i) {
+        const int v = first + i;
+        double c[6];
+        env_coefficients(b->attack[v], b->decay[v], b->sustain[v], b->release[v], kDt,
+                         b->overshoot[v], c);
+        for (int k = 0; k < 6; ++k)
+            coef[(size_t)k * count + i] = c[k];
+        coef[(size_t)6 * count + i] = b->sustain[v];
+        flags[i] = (b->loop[v] ? 1u : 0u) | (b->retrigger[v] ? 2u : 0u);
+    }
+    for (int k = 0; k < 7; ++k)
+        HIP_TRY(hipMemcpyAsync(b->env_coef.p + (size_t)k * b->n + first, &coef[(size_t)k * count],
+                               sizeof(double) * count, hipMemcpyHostToDevice, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(b->env_flags.p + first, flags.data(), sizeof(uint32_t) * count,
+                           hipMemcpyHostToDevice, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+static int upload_gains(klmi_bank *b, int first, int count)
+{
+    std::vector<double> gl(count), gr(count);
+    for (int i = 0; i < count; ++i) {
+        const int v = first + i;
+        if (b->desc.stereo) {
+            double lr[2];
+            panning(b->pan[v], b->desc.pan_mode, b->desc.has_pan_law, b->desc.pan_law, lr);
+            gl[i] = b->gain[v] * lr[0];  // mixer.py:99  (gain * pan) * channel
+            gr[i] = b->gain[v] * lr[1];
+        } else {
+            gl[i] = b->gain[v];
+            gr[i] = 0.;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(b->gain_l.p + first, gl.data(), sizeof(double) * count,
+                           hipMemcpyHostToDevice, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(b->gain_r.p + first, gr.data(), sizeof(double) * count,
+                           hipMemcpyHostToDevice, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+template <typename T>
+static int fill_device(klmi_bank *b, T *dst, size_t count, T value)
+{
+    std::vector<T> h(count, value);
+    HIP_TRY(hipMemcpy(dst, h.data(), sizeof(T) * count, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int bank_init_reverb(klmi_bank *b);
+
+extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_desc *desc,
+                                klmi_bank **out)
+{
+    TRY(use(ctx));
+    if (!out || !desc)
+        return fail(KLMI_E_ARG, "klmi_bank_create: null argument");
+    if (n_voices <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_create: n_voices must be positive, got %d", n_voices);
+    if (desc->pan_mode < 0 || desc->pan_mode > 2)
+        return fail(KLMI_E_ARG, "Invalid panning mode %d!", desc->pan_mode);
+    if (desc->has_pan_law && desc->pan_law > 0)
+        return fail(KLMI_E_ARG, "Pan law has to be negative!");
+    klmi_bank *b = new klmi_bank;
+    b->ctx = ctx;
+    b->n = n_voices;
+    b->desc = *desc;
+    b->mix_divisor = n_voices > 1 ? (double)n_voices : 1.;  // mixer.py:46-47
+    const size_t n = (size_t)n_voices;
+    // defaults: ADSR(.1,.2,.8,1.) envelopes.py:66, overshoot 1e-3, Filter 440 Hz effects.py:353
+    b->attack.assign(n, .1);
+    b->decay.assign(n, .2);
+    b->sustain.assign(n, .8);
+    b->release.assign(n, 1.);
+    b->overshoot.assign(n, 1e-3);
+    b->gain.assign(n, 1.);  // mixer.py:11
+    b->pan.assign(n, 0.);   // panning.py:20
+    b->loop.assign(n, 0);
+    b->retrigger.assign(n, 0);
+
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) {
+        if (e == hipSuccess)
+            e = r;
+    };
+    chk(b->duty.alloc(n));
+    chk(b->env_coef.alloc(7 * n));
+    chk(b->gain_l.alloc(n));
+    chk(b->gain_r.alloc(n));
+    chk(b->wave.alloc(n));
+    chk(b->env_flags.alloc(n));
+    chk(b->state_f64.alloc(SL_F64_COUNT * n));
+    chk(b->state_u32.alloc(SL_U32_COUNT * n));
+    chk(b->backup_f64.alloc(SL_F64_COUNT * n));
+    chk(b->backup_u32.alloc(SL_U32_COUNT * n));
+    chk(b->ev_offset.alloc(n + 1));
+    chk(b->ev_block.alloc(1));
+    chk(b->ev_kind.alloc(1));
+    chk(b->ev_index.alloc(1));
+    chk(b->ev_velocity.alloc(1));
+    chk(b->ev_frequency.alloc(1));
+    if (e != hipSuccess) {
+        delete b;
+        return fail(KLMI_E_MEMORY, "klmi_bank_create: device allocation failed: %s",
+                    hipGetErrorString(e));
+    }
+    int rc = 0;
+    auto step = [&](int r) {
+        if (rc == 0)
+            rc = r;
+    };
+    if (hipMemset(b->state_f64.p, 0, sizeof(double) * SL_F64_COUNT * n) != hipSuccess ||
+        hipMemset(b->state_u32.p, 0, sizeof(uint32_t) * SL_U32_COUNT * n) != hipSuccess ||
+        hipMemset(b->ev_offset.p, 0, sizeof(uint32_t) * (n + 1)) != hipSuccess ||
+        hipMemset(b->wave.p, 0, sizeof(int32_t) * n) != hipSuccess)
+        step(fail(KLMI_E_DEVICE, "klmi_bank_create: memset failed"));
+    step(fill_device<double>(b, b->duty.p, n, .5));           // oscillators.py:245
+    step(fill_device<double>(b, b->f64(SL_FREQ), n, 440.));   // oscillators.py:121
+    step(fill_device<uint32_t>(b, b->u32(SL_COEF_INDEX), n,
+                               (uint32_t)grid_index(ctx->grid.data(), 440.)));
+    if (rc == 0)
+        step(upload_env(b, 0, n_voices));
+    if (rc == 0)
+        step(upload_gains(b, 0, n_voices));
+    if (rc == 0 && desc->has_reverb)
+        step(bank_init_reverb(b));
+    if (rc != 0) {
+        delete b;
+        return rc;
+    }
+    ctx->live_objects++;
+    *out = b;
+    return 0;
+}
+
+static void destroy_events(klmi_bank *b)
+{
+    for (auto e : b->ev_start)
+        (void)hipEventDestroy(e);
+    for (auto e : b->ev_stop)
+        (void)hipEventDestroy(e);
+    b->ev_start.clear();
+    b->ev_stop.clear();
+}
+
+extern "C" int klmi_bank_destroy(klmi_bank *bank)
+{
+    if (!bank)
+        return 0;
+    (void)hipSetDevice(bank->ctx->device);
+    (void)hipStreamSynchronize(bank->ctx->stream);
+    destroy_events(bank);
+    bank->ctx->live_objects--;
+    delete bank;
+    return 0;
+}
+
+static int check_range(klmi_bank *b, int first, int count, const void *host, const char *what)
+{
+    if (!b)
+        return fail(KLMI_E_ARG, "%s: null bank", what);
+    if (!host)
+        return fail(KLMI_E_ARG, "%s: null host pointer", what);
+    if (first < 0 || count < 0 || (long)first + count > b->n)
+        return fail(KLMI_E_ARG, "%s: range [%d, %d) outside bank of %d voices", what, first,
+                    first + count, b->n);
+    return 0;
+}
+
+static int state_slot(int field, bool *is_u32)
+{
+    *is_u32 = false;
+    switch (field) {
+    case KLMI_F_PHASE: return SL_PHASE;
+    case KLMI_F_ENV_VALUE: return SL_ENV_VALUE;
+    case KLMI_F_Z0: return SL_Z0;
+    case KLMI_F_Z1: return SL_Z1;
+    case KLMI_F_FREQUENCY: return SL_FREQ;
+    case KLMI_F_AMPLITUDE: return SL_AMP;
+    case KLMI_F_ENV_STAGE:
+    case KLMI_F_ENV_ENABLED: *is_u32 = true; return SL_ENV_STATE;
+    default: return -1;
+    }
+}
+
+extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int count,
+                                    const double *host)
+{
+    TRY(check_range(b, first, count, host, "klmi_bank_set_params"));
+    TRY(use(b->ctx));
+    if (count == 0)
+        return 0;
+    hipStream_t st = b->ctx->stream;
+    switch (field) {
+    case KLMI_F_FREQUENCY:
+    case KLMI_F_AMPLITUDE: {
+        const int slot = field == KLMI_F_FREQUENCY ? SL_FREQ : SL_AMP;
+        HIP_TRY(hipMemcpyAsync(b->f64(slot) + first, host, sizeof(double) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    case KLMI_F_DUTY:
+        HIP_TRY(hipMemcpyAsync(b->duty.p + first, host, sizeof(double) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    case KLMI_F_WAVE: {
+        std::vector<int32_t> w(count);
+        for (int i = 0; i < count; ++i) {
+            if (!(host[i] >= 0. && host[i] <= (double)KLMI_WAVE_EXTERNAL))
+                return fail(KLMI_E_ARG, "klmi_bank_set_params: unknown wave id %g", host[i]);
+            w[i] = (int32_t)host[i];
+        }
+        HIP_TRY(hipMemcpyAsync(b->wave.p + first, w.data(), sizeof(int32_t) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    case KLMI_F_ATTACK:
+    case KLMI_F_DECAY:
+    case KLMI_F_RELEASE:
+    case KLMI_F_SUSTAIN:
+    case KLMI_F_OVERSHOOT: {
+        static const char *names[] = {"attack", "decay", "sustain", "release", "overshoot"};
+        const char *name = names[field - KLMI_F_ATTACK];
+        for (int i = 0; i < count; ++i) {
+            if (field == KLMI_F_SUSTAIN) {
+                if (!(host[i] >= 0. && host[i] <= 1.))
+                    return fail(KLMI_E_ARG, "sustain not within bounds!");  // _envelope.c:299-302
+            } else if (!(host[i] >= 0.)) {
+                return fail(KLMI_E_ARG, "%s must be positive!", name);      // _envelope.c:229-232
+            }
+        }
+        std::vector<double> &dst = field == KLMI_F_ATTACK    ? b->attack
+                                   : field == KLMI_F_DECAY   ? b->decay
+                                   : field == KLMI_F_SUSTAIN ? b->sustain
+                                   : field == KLMI_F_RELEASE ? b->release
+                                                             : b->overshoot;
+        for (int i = 0; i < count; ++i)
+            dst[first + i] = field == KLMI_F_OVERSHOOT ? clip(host[i], 1e-9, 1e9) : host[i];
+        return upload_env(b, first, count);
+    }
+    case KLMI_F_LOOP:
+    case KLMI_F_RETRIGGER: {
+        std::vector<uint8_t> &dst = field == KLMI_F_LOOP ? b->loop : b->retrigger;
+        for (int i = 0; i < count; ++i)
+            dst[first + i] = host[i] != 0.;
+        return upload_env(b, first, count);
+    }
+    case KLMI_F_CUTOFF: {
+        std::vector<int32_t> idx(count);
+        for (int i = 0; i < count; ++i)
+            idx[i] = grid_index(b->ctx->grid.data(), host[i]);
+        HIP_TRY(hipMemcpyAsync(b->u32(SL_COEF_INDEX) + first, idx.data(), sizeof(int32_t) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    case KLMI_F_GAIN:
+    case KLMI_F_PAN: {
+        std::vector<double> &dst = field == KLMI_F_GAIN ? b->gain : b->pan;
+        std::copy(host, host + count, dst.begin() + first);
+        return upload_gains(b, first, count);
+    }
+    default:
+        return fail(KLMI_E_ARG, "klmi_bank_set_params: field %d is not a parameter", field);
+    }
+}
+
+extern "C" int klmi_bank_state_get(klmi_bank *b, int field, int first, int count, double *host)
+{
+    TRY(check_range(b, first, count, host, "klmi_bank_state_get"));
+    TRY(use(b->ctx));
+    bool is_u32;
+    const int slot = state_slot(field, &is_u32);
+    if (slot < 0)
+        return fail(KLMI_E_ARG, "klmi_bank_state_get: field %d is not a state field", field);
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (!is_u32) {
+        HIP_TRY(hipMemcpy(host, b->f64(slot) + first, sizeof(double) * count,
+                          hipMemcpyDeviceToHost));
+        return 0;
+    }
+    std::vector<uint32_t> raw(count);
+    HIP_TRY(hipMemcpy(raw.data(), b->u32(slot) + first, sizeof(uint32_t) * count,
+                      hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i)
+        host[i] = field == KLMI_F_ENV_STAGE ? (double)(raw[i] & 7u) : (double)((raw[i] >> 8) & 1u);
+    return 0;
+}
+
+extern "C" int klmi_bank_state_set(klmi_bank *b, int field, int first, int count,
+                                   const double *host)
+{
+    TRY(check_range(b, first, count, host, "klmi_bank_state_set"));
+    TRY(use(b->ctx));
+    bool is_u32;
+    const int slot = state_slot(field, &is_u32);
+    if (slot < 0)
+        return fail(KLMI_E_ARG, "klmi_bank_state_set: field %d is not a state field", field);
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (!is_u32) {
+        HIP_TRY(hipMemcpy(b->f64(slot) + first, host, sizeof(double) * count,
+                          hipMemcpyHostToDevice));
+        return 0;
+    }
+    std::vector<uint32_t> raw(count);
+    HIP_TRY(hipMemcpy(raw.data(), b->u32(slot) + first, sizeof(uint32_t) * count,
+                      hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; ++i) {
+        if (field == KLMI_F_ENV_STAGE) {
+            if (!(host[i] >= 0. && host[i] <= 4.))
+                return fail(KLMI_E_ARG, "klmi_bank_state_set: bad envelope stage %g", host[i]);
+            raw[i] = (raw[i] & ~7u) | (uint32_t)host[i];
+        } else {
+            raw[i] = (raw[i] & ~0x100u) | (host[i] != 0. ? 0x100u : 0u);
+        }
+    }
+    HIP_TRY(hipMemcpy(b->u32(slot) + first, raw.data(), sizeof(uint32_t) * count,
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int klmi_bank_events(klmi_bank *b, const klmi_event *events, size_t n)
+{
+    if (!b)
+        return fail(KLMI_E_ARG, "klmi_bank_events: null bank");
+    if (n && !events)
+        return fail(KLMI_E_ARG, "klmi_bank_events: null events");
+    for (size_t i = 0; i < n; ++i) {
+        if (events[i].voice >= (uint32_t)b->n)
+            return fail(KLMI_E_ARG, "klmi_bank_events: event %zu addresses voice %u of %d", i,
+                        events[i].voice, b->n);
+        if (events[i].kind > KLMI_EV_SET_FREQUENCY)
+            return fail(KLMI_E_ARG, "klmi_bank_events: event %zu has unknown kind %u", i,
+                        events[i].kind);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (events[i].block > 0xFFFFFFFEu - b->block_clock)
+            return fail(KLMI_E_ARG, "klmi_bank_events: event %zu lies too far in the future", i);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        klmi_event e = events[i];
+        e.block += b->block_clock;
+        b->pending.push_back(e);
+    }
+    if (n)
+        b->events_dirty = true;
+    return 0;
+}
+
+extern "C" int klmi_bank_set_mix_divisor(klmi_bank *b, double divisor)
+{
+    if (!b || !(divisor > 0.))
+        return fail(KLMI_E_ARG, "klmi_bank_set_mix_divisor: divisor must be > 0");
+    b->mix_divisor = divisor;
+    return 0;
+}
+
+extern "C" int klmi_bank_set_input(klmi_bank *b, const double *host_x, int n_blocks)
+{
+    if (!b || !host_x || n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_set_input: bad argument");
+    TRY(use(b->ctx));
+    const size_t span = (size_t)n_blocks * kBlock, n = (size_t)b->n;
+    std::vector<double> t(span * n);  // [voice][span] -> [span][voice]
+    for (size_t v = 0; v < n; ++v)
+        for (size_t s = 0; s < span; ++s)
+            t[s * n + v] = host_x[v * span + s];
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(b->ext_input.reserve(span * n));
+    HIP_TRY(hipMemcpy(b->ext_input.p, t.data(), sizeof(double) * span * n, hipMemcpyHostToDevice));
+    b->ext_blocks = n_blocks;
+    b->ext_cursor = 0;
+    return 0;
+}
+
+// Upload the event queue if it changed since the last upload: drop what has
+// been consumed (block < clock), stable-sort by (voice, block), build the
+// per-voice CSR, reset the per-voice cursors.  Renders with an unchanged queue
+// do no host-side event work at all.
+static int sync_events(klmi_bank *b)
+{
+    if (!b->events_dirty)
+        return 0;
+    std::vector<klmi_event> &q = b->pending;
+    q.erase(std::remove_if(q.begin(), q.end(),
+                           [&](const klmi_event &e) { return e.block < b->block_clock; }),
+            q.end());
+    std::stable_sort(q.begin(), q.end(), [](const klmi_event &a, const klmi_event &c) {
+        return a.voice != c.voice ? a.voice < c.voice : a.block < c.block;
+    });
+    const size_t m = q.size();
+    std::vector<uint32_t> offset((size_t)b->n + 1, 0), block(m), kind(m);
+    std::vector<int32_t> index(m);
+    std::vector<double> vel(m), freq(m);
+    for (size_t i = 0; i < m; ++i) {
+        offset[q[i].voice + 1]++;
+        block[i] = q[i].block;
+        kind[i] = q[i].kind;
+        vel[i] = q[i].velocity;
+        freq[i] = q[i].frequency;
+        index[i] = q[i].kind == KLMI_EV_SET_CUTOFF ? grid_index(b->ctx->grid.data(), q[i].frequency)
+                                                   : 0;
+    }
+    for (int v = 0; v < b->n; ++v)
+        offset[v + 1] += offset[v];
+    hipStream_t st = b->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));  // nothing in flight may still read the old arrays
+    HIP_TRY(b->ev_block.reserve(m));
+    HIP_TRY(b->ev_kind.reserve(m));
+    HIP_TRY(b->ev_index.reserve(m));
+    HIP_TRY(b->ev_velocity.reserve(m));
+    HIP_TRY(b->ev_frequency.reserve(m));
+    HIP_TRY(hipMemcpyAsync(b->ev_offset.p, offset.data(), sizeof(uint32_t) * offset.size(),
+                           hipMemcpyHostToDevice, st));
+    if (m) {
+        HIP_TRY(hipMemcpyAsync(b->ev_block.p, block.data(), sizeof(uint32_t) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->ev_kind.p, kind.data(), sizeof(uint32_t) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->ev_index.p, index.data(), sizeof(int32_t) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->ev_velocity.p, vel.data(), sizeof(double) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->ev_frequency.p, freq.data(), sizeof(double) * m,
+                               hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemsetAsync(b->u32(SL_EV_CURSOR), 0, sizeof(uint32_t) * b->n, st));
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors die here
+    b->events_dirty = false;
+    return 0;
+}
+
+template <int MODE> static size_t smem_bytes()
+{
+    using TT = TileTraits<MODE>;
+    const int planes = TT::planes ? TT::planes : 1;
+    size_t bytes = sizeof(typename TT::T) * (size_t)kWavesPerGroup * planes * TT::chunk * TT::stride;
+    if (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO)
+        bytes += sizeof(float) * (size_t)kWavesPerGroup * TT::planes * TT::chunk;
+    return bytes;
+}
+
+template <bool ENV, bool FILT, int MODE>
+static hipError_t launch_voice(hipStream_t st, const BankView &view, int first, int count,
+                               int block_base, uint32_t clock_base, int n_blocks, int span_total,
+                               float *partial, void *out)
+{
+    static bool configured[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t smem = smem_bytes<MODE>();
+    auto kernel = voice_kernel<ENV, FILT, MODE>;
+    if (dev < 16 && !configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess)
+            return e;
+        configured[dev] = true;
+    }
+    const int groups = (count + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(kernel, dim3(groups), dim3(kGroup), smem, st, view, first, count,
+                       block_base, clock_base, n_blocks, span_total, partial, out);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const BankView &view,
+                                 int first, int count, int block_base, uint32_t clock_base,
+                                 int n_blocks, int span_total, float *partial, void *out)
+{
+    if (env && filt)
+        return launch_voice<true, true, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
+                                              span_total, partial, out);
+    if (env)
+        return launch_voice<true, false, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
+                                               span_total, partial, out);
+    if (filt)
+        return launch_voice<false, true, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
+                                               span_total, partial, out);
+    return launch_voice<false, false, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
+                                            span_total, partial, out);
+}
+
+static int check_external(klmi_bank *b, int n_blocks)
+{
+    // W_EXTERNAL voices read ext_input; make sure it covers the span
+    if (b->ext_input.p == nullptr || b->ext_blocks - b->ext_cursor < n_blocks) {
+        // only an error if some voice actually is external; the bank tracks that on set_params
+        std::vector<int32_t> w(b->n);
+        HIP_TRY(hipMemcpy(w.data(), b->wave.p, sizeof(int32_t) * b->n, hipMemcpyDeviceToHost));
+        for (int v = 0; v < b->n; ++v)
+            if (w[v] == W_EXTERNAL)
+                return fail(KLMI_E_STATE,
+                            "voice %d uses KLMI_WAVE_EXTERNAL but only %d blocks of external "
+                            "input are left, %d needed", v, b->ext_blocks - b->ext_cursor,
+                            n_blocks);
+    }
+    return 0;
+}
+
+static int timing_begin(klmi_bank *b, int idx)
+{
+    while ((int)b->ev_start.size() <= idx) {
+        hipEvent_t a, c;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&c));
+        b->ev_start.push_back(a);
+        b->ev_stop.push_back(c);
+    }
+    HIP_TRY(hipEventRecord(b->ev_start[idx], b->ctx->stream));
+    return 0;
+}
+
+static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix);
+
+static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix)
+{
+    if (n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_render: n_blocks must be positive, got %d", n_blocks);
+    TRY(check_external(b, n_blocks));
+    TRY(sync_events(b));
+    if (b->desc.has_reverb)
+        return render_reverb(b, n_blocks, dev_mix);
+    hipStream_t st = b->ctx->stream;
+    const int planes = b->desc.stereo ? 2 : 1;
+    const int groups = (b->n + kGroup - 1) / kGroup;
+    // blocks per launch: keep the per-group partial buses within ~64 MiB
+    const size_t per_block = (size_t)groups * planes * kBlock * sizeof(float);
+    int bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, ((size_t)64 << 20) / per_block));
+    HIP_TRY(b->partial.reserve((size_t)groups * planes * kBlock * bpl));
+    BankView view = make_view(b);
+    b->timed_launches = 0;
+    for (int base = 0; base < n_blocks; base += bpl) {
+        const int nb = std::min(bpl, n_blocks - base);
+        TRY(timing_begin(b, b->timed_launches));
+        hipError_t e =
+            b->desc.stereo
+                ? dispatch_voice<OUT_MIX_STEREO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
+                                                 b->n, base, b->block_clock + (uint32_t)base, nb, 0,
+                                                 b->partial.p, nullptr)
+                : dispatch_voice<OUT_MIX_MONO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
+                                               b->n, base, b->block_clock + (uint32_t)base, nb, 0,
+                                                 b->partial.p, nullptr);
+        if (e != hipSuccess)
+            return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
+        b->timed_launches++;
+        const size_t bus_len = (size_t)nb * planes * kBlock;
+        hipLaunchKernelGGL(bus_reduce_kernel, dim3((unsigned)((bus_len + 255) / 256)), dim3(256), 0,
+                           st, b->partial.p, groups, bus_len, b->mix_divisor,
+                           dev_mix + (size_t)base * planes * kBlock);
+        HIP_TRY(hipGetLastError());
+    }
+    b->block_clock += (uint32_t)n_blocks;
+    if (b->ext_input.p)
+        b->ext_cursor = std::min(b->ext_blocks, b->ext_cursor + n_blocks);
+    return 0;
+}
+
+extern "C" int klmi_bank_render_device(klmi_bank *b, int n_blocks, float *dev_mix)
+{
+    if (!b || !dev_mix)
+        return fail(KLMI_E_ARG, "klmi_bank_render_device: null argument");
+    TRY(use(b->ctx));
+    return render_mix(b, n_blocks, dev_mix);
+}
+
+extern "C" int klmi_bank_render(klmi_bank *b, int n_blocks, float *host_mix)
+{
+    if (!b || !host_mix)
+        return fail(KLMI_E_ARG, "klmi_bank_render: null argument");
+    TRY(use(b->ctx));
+    if (n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_render: n_blocks must be positive, got %d", n_blocks);
+    const size_t len = (size_t)n_blocks * (b->desc.stereo ? 2 : 1) * kBlock;
+    HIP_TRY(b->dev_mix.reserve(len));
+    TRY(render_mix(b, n_blocks, b->dev_mix.p));
+    HIP_TRY(hipMemcpyAsync(host_mix, b->dev_mix.p, sizeof(float) * len, hipMemcpyDeviceToHost,
+                           b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+// Preview: snapshot state, render, restore; the event queue is not consumed.
+template <int MODE>
+static int render_preview(klmi_bank *b, int first, int count, int n_blocks, void *dev_out)
+{
+    if (n_blocks <= 0 || count <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices: n_blocks and count must be positive");
+    if (first < 0 || (long)first + count > b->n)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices: range [%d, %d) outside bank of %d voices",
+                    first, first + count, b->n);
+    if (b->desc.has_reverb)
+        return fail(KLMI_E_STATE, "klmi_bank_render_voices: previews of reverb banks are not "
+                                  "available; use klmi_bank_render");
+    TRY(check_external(b, n_blocks));
+    TRY(sync_events(b));
+    hipStream_t st = b->ctx->stream;
+    const size_t n = (size_t)b->n;
+    HIP_TRY(hipMemcpyAsync(b->backup_f64.p, b->state_f64.p, sizeof(double) * SL_F64_COUNT * n,
+                           hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->backup_u32.p, b->state_u32.p, sizeof(uint32_t) * SL_U32_COUNT * n,
+                           hipMemcpyDeviceToDevice, st));
+    BankView view = make_view(b);
+    b->timed_launches = 0;
+    TRY(timing_begin(b, 0));
+    hipError_t e = dispatch_voice<MODE>(b->desc.has_env, b->desc.has_filter, st, view, first, count,
+                                        0, b->block_clock, n_blocks, n_blocks * kBlock, nullptr,
+                                        dev_out);
+    if (e != hipSuccess)
+        return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipEventRecord(b->ev_stop[0], st));
+    b->timed_launches = 1;
+    HIP_TRY(hipMemcpyAsync(b->state_f64.p, b->backup_f64.p, sizeof(double) * SL_F64_COUNT * n,
+                           hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(b->state_u32.p, b->backup_u32.p, sizeof(uint32_t) * SL_U32_COUNT * n,
+                           hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int klmi_bank_render_voices_device(klmi_bank *b, int first, int count, int n_blocks,
+                                              float *dev_out)
+{
+    if (!b || !dev_out)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices_device: null argument");
+    TRY(use(b->ctx));
+    return render_preview<OUT_VOICES_F32>(b, first, count, n_blocks, dev_out);
+}
+
+extern "C" int klmi_bank_render_voices(klmi_bank *b, int first, int count, int n_blocks,
+                                       float *host_out)
+{
+    if (!b || !host_out)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices: null argument");
+    TRY(use(b->ctx));
+    if (n_blocks <= 0 || count <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices: n_blocks and count must be positive");
+    const size_t len = (size_t)count * n_blocks * kBlock;
+    HIP_TRY(b->dev_voices_f32.reserve(len));
+    TRY(render_preview<OUT_VOICES_F32>(b, first, count, n_blocks, b->dev_voices_f32.p));
+    HIP_TRY(hipMemcpyAsync(host_out, b->dev_voices_f32.p, sizeof(float) * len,
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+extern "C" int klmi_bank_render_voices_f64(klmi_bank *b, int first, int count, int n_blocks,
+                                           double *host_out)
+{
+    if (!b || !host_out)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices_f64: null argument");
+    TRY(use(b->ctx));
+    if (n_blocks <= 0 || count <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_render_voices_f64: n_blocks and count must be positive");
+    const size_t len = (size_t)count * n_blocks * kBlock;
+    HIP_TRY(b->dev_voices_f64.reserve(len));
+    TRY(render_preview<OUT_VOICES_F64>(b, first, count, n_blocks, b->dev_voices_f64.p));
+    HIP_TRY(hipMemcpyAsync(host_out, b->dev_voices_f64.p, sizeof(double) * len,
+                           hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+extern "C" int klmi_bank_last_kernel_ms(klmi_bank *b, float *voice_ms, int *launches)
+{
+    if (!b)
+        return fail(KLMI_E_ARG, "klmi_bank_last_kernel_ms: null bank");
+    TRY(use(b->ctx));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    float total = 0.f;
+    for (int i = 0; i < b->timed_launches; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev_start[i], b->ev_stop[i]));
+        total += ms;
+    }
+    if (voice_ms)
+        *voice_ms = total;
+    if (launches)
+        *launches = b->timed_launches;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// reverb banks
+// ---------------------------------------------------------------------------------
+static int bank_init_reverb(klmi_bank *b)
+{
+    const klmi_chain_desc &d = b->desc;
+    if (d.reverb_n_echos <= 0 || d.reverb_n_echos > kMaxEchos)
+        return fail(KLMI_E_ARG, "Reverb: nEchos must lie in 1..%d, got %d", kMaxEchos,
+                    d.reverb_n_echos);
+    b->taps.resize(d.reverb_n_echos);
+    b->alphas.resize(d.reverb_n_echos);
+    TRY(klmi_reverb_design(d.reverb_decay, d.reverb_pre_delay, d.reverb_n_echos, b->taps.data(),
+                           b->alphas.data()));
+    ReverbState &r = b->reverb;
+    r.n_echos = d.reverb_n_echos;
+    r.n = b->n;
+    r.dry_wet = clip(d.reverb_dry_wet, 0., 1.);  // effects.py:586
+    size_t total = 0;
+    int min_tap = b->taps[0];
+    for (int k = 0; k < r.n_echos; ++k) {
+        r.length[k] = b->taps[k];
+        r.alpha[k] = b->alphas[k];
+        r.offset[k] = (long long)total;
+        total += (size_t)b->taps[k];
+        min_tap = std::min(min_tap, b->taps[k]);
+    }
+    r.min_length = min_tap;
+    b->ring_pos.assign(r.n_echos, 0);
+    hipError_t e = b->rings.alloc(total * (size_t)b->n);
+    if (e != hipSuccess)
+        return fail(KLMI_E_MEMORY, "Reverb: could not allocate %zu ring samples: %s",
+                    total * (size_t)b->n, hipGetErrorString(e));
+    HIP_TRY(hipMemset(b->rings.p, 0, sizeof(double) * total * (size_t)b->n));  // _filters.c:57
+    r.rings = b->rings.p;
+    return 0;
+}
+
+static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
+{
+    hipStream_t st = b->ctx->stream;
+    ReverbState &r = b->reverb;
+    const size_t n = (size_t)b->n;
+    // time slab: as many samples as are independent of each other (< shortest ring),
+    // whole blocks when possible
+    int slab = std::min(r.min_length, 1024);
+    if (slab >= kBlock)
+        slab = (slab / kBlock) * kBlock;
+    const int slab_blocks = std::max(1, slab / kBlock);
+    const int chunk_blocks = std::min(n_blocks, std::max(slab_blocks, 64));
+    HIP_TRY(b->bus_f64.reserve((size_t)chunk_blocks * kBlock * n));
+    const int wave_groups = (b->n + 63) / 64;
+    HIP_TRY(b->rv_partial.reserve((size_t)wave_groups * chunk_blocks * kBlock));
+    BankView view = make_view(b);
+    b->timed_launches = 0;
+    for (int base = 0; base < n_blocks; base += chunk_blocks) {
+        const int nb = std::min(chunk_blocks, n_blocks - base);
+        // 1) dry voices for nb blocks -> bus_f64[sample][voice]
+        hipError_t e = dispatch_voice<OUT_BUS_F64>(b->desc.has_env, b->desc.has_filter, st, view, 0,
+                                                   b->n, base, b->block_clock + (uint32_t)base, nb,
+                                                   0, nullptr, b->bus_f64.p);
+        if (e != hipSuccess)
+            return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
+        // 2) combs + dry/wet + cross-voice sum, one launch per independent time slab
+        const int total = nb * kBlock;
+        for (int s0 = 0; s0 < total; s0 += slab) {
+            const int ns = std::min(slab, total - s0);
+            for (int k = 0; k < r.n_echos; ++k)
+                r.position[k] = b->ring_pos[k];
+            TRY(timing_begin(b, b->timed_launches));
+            const dim3 grid((unsigned)wave_groups, (unsigned)((ns + kReverbSamplesPerWave - 1) /
+                                                              kReverbSamplesPerWave));
+            hipLaunchKernelGGL(reverb_kernel, grid, dim3(64), 0, st, r,
+                               b->bus_f64.p + (size_t)s0 * n, ns, b->gain_l.p,
+                               b->rv_partial.p + (size_t)s0, (size_t)chunk_blocks * kBlock);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
+            b->timed_launches++;
+            for (int k = 0; k < r.n_echos; ++k)
+                b->ring_pos[k] = (b->ring_pos[k] + ns) % r.length[k];
+        }
+        const size_t bus_len = (size_t)total;
+        hipLaunchKernelGGL(bus_reduce_strided_kernel, dim3((unsigned)((bus_len + 255) / 256)),
+                           dim3(256), 0, st, b->rv_partial.p, wave_groups,
+                           (size_t)chunk_blocks * kBlock, bus_len, b->mix_divisor,
+                           dev_mix + (size_t)base * kBlock);
+        HIP_TRY(hipGetLastError());
+    }
+    b->block_clock += (uint32_t)n_blocks;
+    if (b->ext_input.p)
+        b->ext_cursor = std::min(b->ext_blocks, b->ext_cursor + n_blocks);
+    return 0;
+}
+
+extern "C" int klmi_bank_reverb_state_get(klmi_bank *b, int voice, double *rings,
+                                          int32_t *positions)
+{
+    if (!b || !rings || !positions)
+        return fail(KLMI_E_ARG, "klmi_bank_reverb_state_get: null argument");
+    if (!b->desc.has_reverb)
+        return fail(KLMI_E_STATE, "klmi_bank_reverb_state_get: bank has no reverb");
+    if (voice < 0 || voice >= b->n)
+        return fail(KLMI_E_ARG, "klmi_bank_reverb_state_get: voice %d out of range", voice);
+    TRY(use(b->ctx));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    size_t total = 0;
+    for (int t : b->taps)
+        total += (size_t)t;
+    // rings are [slot][voice]: strided gather of one voice
+    HIP_TRY(hipMemcpy2D(rings, sizeof(double), b->rings.p + voice, sizeof(double) * b->n,
+                        sizeof(double), total, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < b->taps.size(); ++k)
+        positions[k] = b->ring_pos[k];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// envelope batch
+// ---------------------------------------------------------------------------------
+struct klmi_env {
+    klmi_ctx *ctx = nullptr;
+    int count = 0;
+    double dt = kDt;
+    std::vector<double> attack, decay, sustain, release, overshoot;
+    std::vector<uint8_t> loop, retrigger;
+    DevBuf<double> coef, value, out;
+    DevBuf<uint32_t> flags, state;
+};
+
+static int env_upload(klmi_env *e, int first, int count)
+{
+    std::vector<double> coef((size_t)7 * count);
+    std::vector<uint32_t> flags(count);
+    for (int i = 0; i < count; ++i) {
+        const int v = first + i;
+        double c[6];
+        env_coefficients(e->attack[v], e->decay[v], e->sustain[v], e->release[v], e->dt,
+                         e->overshoot[v], c);
+        for (int k = 0; k < 6; ++k)
+            coef[(size_t)k * count + i] = c[k];
+        coef[(size_t)6 * count + i] = e->sustain[v];
+        flags[i] = (e->loop[v] ? 1u : 0u) | (e->retrigger[v] ? 2u : 0u);
+    }
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    for (int k = 0; k < 7; ++k)
+        HIP_TRY(hipMemcpy(e->coef.p + (size_t)k * e->count + first, &coef[(size_t)k * count],
+                          sizeof(double) * count, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->flags.p + first, flags.data(), sizeof(uint32_t) * count,
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int klmi_env_create(klmi_ctx *ctx, int count, double attack, double decay,
+                               double sustain, double release, double dt, double overshoot,
+                               int retrigger, int loop, klmi_env **out)
+{
+    TRY(use(ctx));
+    if (!out || count <= 0)
+        return fail(KLMI_E_ARG, "klmi_env_create: bad argument");
+    // The reference's constructor (_envelope.c:518-535) stores its arguments unchecked;
+    // only the setters validate.  dt must be usable as a divisor here.
+    if (!(dt > 0.))
+        return fail(KLMI_E_ARG, "klmi_env_create: dt must be > 0");
+    klmi_env *e = new klmi_env;
+    e->ctx = ctx;
+    e->count = count;
+    e->dt = dt;
+    e->attack.assign(count, attack);
+    e->decay.assign(count, decay);
+    e->sustain.assign(count, sustain);
+    e->release.assign(count, release);
+    e->overshoot.assign(count, clip(overshoot, 1e-9, 1e9));  // _envelope.c:532
+    e->loop.assign(count, loop != 0);
+    e->retrigger.assign(count, retrigger != 0);
+    hipError_t err = e->coef.alloc((size_t)7 * count);
+    if (err == hipSuccess) err = e->value.alloc(count);
+    if (err == hipSuccess) err = e->flags.alloc(count);
+    if (err == hipSuccess) err = e->state.alloc(count);
+    if (err == hipSuccess) err = hipMemset(e->value.p, 0, sizeof(double) * count);
+    if (err == hipSuccess) err = hipMemset(e->state.p, 0, sizeof(uint32_t) * count);
+    if (err != hipSuccess) {
+        delete e;
+        return fail(KLMI_E_MEMORY, "klmi_env_create: %s", hipGetErrorString(err));
+    }
+    int rc = env_upload(e, 0, count);
+    if (rc != 0) {
+        delete e;
+        return rc;
+    }
+    ctx->live_objects++;
+    *out = e;
+    return 0;
+}
+
+extern "C" int klmi_env_destroy(klmi_env *env)
+{
+    if (!env)
+        return 0;
+    (void)hipSetDevice(env->ctx->device);
+    (void)hipStreamSynchronize(env->ctx->stream);
+    env->ctx->live_objects--;
+    delete env;
+    return 0;
+}
+
+static int env_range(klmi_env *e, int first, int count, const void *host, const char *what)
+{
+    if (!e || !host)
+        return fail(KLMI_E_ARG, "%s: null argument", what);
+    if (first < 0 || count < 0 || (long)first + count > e->count)
+        return fail(KLMI_E_ARG, "%s: range [%d, %d) outside batch of %d", what, first,
+                    first + count, e->count);
+    return 0;
+}
+
+extern "C" int klmi_env_set(klmi_env *e, int field, int first, int count, const double *host)
+{
+    TRY(env_range(e, first, count, host, "klmi_env_set"));
+    TRY(use(e->ctx));
+    switch (field) {
+    case KLMI_F_ATTACK:
+    case KLMI_F_DECAY:
+    case KLMI_F_RELEASE:
+    case KLMI_F_OVERSHOOT:
+        for (int i = 0; i < count; ++i)
+            if (!(host[i] >= 0.))
+                return fail(KLMI_E_ARG, "%s must be positive!",
+                            field == KLMI_F_ATTACK ? "attack" : field == KLMI_F_DECAY ? "decay"
+                            : field == KLMI_F_RELEASE ? "release" : "overshoot");
+        break;
+    case KLMI_F_SUSTAIN:
+        for (int i = 0; i < count; ++i)
+            if (!(host[i] >= 0. && host[i] <= 1.))
+                return fail(KLMI_E_ARG, "sustain not within bounds!");
+        break;
+    case KLMI_F_LOOP:
+    case KLMI_F_RETRIGGER:
+        break;
+    case KLMI_F_ENV_VALUE:
+        HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+        HIP_TRY(hipMemcpy(e->value.p + first, host, sizeof(double) * count, hipMemcpyHostToDevice));
+        return 0;
+    default:
+        return fail(KLMI_E_ARG, "klmi_env_set: field %d not settable", field);
+    }
+    for (int i = 0; i < count; ++i) {
+        const int v = first + i;
+        switch (field) {
+        case KLMI_F_ATTACK: e->attack[v] = host[i]; break;
+        case KLMI_F_DECAY: e->decay[v] = host[i]; break;
+        case KLMI_F_SUSTAIN: e->sustain[v] = host[i]; break;
+        case KLMI_F_RELEASE: e->release[v] = host[i]; break;
+        case KLMI_F_OVERSHOOT: e->overshoot[v] = clip(host[i], 1e-9, 1e9); break;  // :374
+        case KLMI_F_LOOP: e->loop[v] = host[i] != 0.; break;
+        case KLMI_F_RETRIGGER: e->retrigger[v] = host[i] != 0.; break;
+        }
+    }
+    return env_upload(e, first, count);
+}
+
+extern "C" int klmi_env_get(klmi_env *e, int field, int first, int count, double *host)
+{
+    TRY(env_range(e, first, count, host, "klmi_env_get"));
+    TRY(use(e->ctx));
+    std::vector<uint32_t> raw;
+    switch (field) {
+    case KLMI_F_ATTACK: std::copy_n(e->attack.begin() + first, count, host); return 0;
+    case KLMI_F_DECAY: std::copy_n(e->decay.begin() + first, count, host); return 0;
+    case KLMI_F_SUSTAIN: std::copy_n(e->sustain.begin() + first, count, host); return 0;
+    case KLMI_F_RELEASE: std::copy_n(e->release.begin() + first, count, host); return 0;
+    case KLMI_F_OVERSHOOT: std::copy_n(e->overshoot.begin() + first, count, host); return 0;
+    case KLMI_F_LOOP:
+        for (int i = 0; i < count; ++i) host[i] = e->loop[first + i];
+        return 0;
+    case KLMI_F_RETRIGGER:
+        for (int i = 0; i < count; ++i) host[i] = e->retrigger[first + i];
+        return 0;
+    case KLMI_F_ENV_VALUE:
+        HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+        HIP_TRY(hipMemcpy(host, e->value.p + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+        return 0;
+    case KLMI_F_ENV_STAGE:
+    case KLMI_F_ENV_ENABLED:
+        raw.resize(count);
+        HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+        HIP_TRY(hipMemcpy(raw.data(), e->state.p + first, sizeof(uint32_t) * count,
+                          hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; ++i)
+            host[i] = field == KLMI_F_ENV_STAGE ? (double)(raw[i] & 7u)
+                                                : (double)((raw[i] >> 8) & 1u);
+        return 0;
+    default:
+        return fail(KLMI_E_ARG, "klmi_env_get: unknown field %d", field);
+    }
+}
+
+extern "C" int klmi_env_gate(klmi_env *e, int first, int count, int on)
+{
+    if (!e)
+        return fail(KLMI_E_ARG, "klmi_env_gate: null envelope");
+    if (first < 0 || count < 0 || (long)first + count > e->count)
+        return fail(KLMI_E_ARG, "klmi_env_gate: range outside batch");
+    TRY(use(e->ctx));
+    if (count == 0)
+        return 0;
+    hipLaunchKernelGGL(env_gate_kernel, dim3((count + 255) / 256), dim3(256), 0, e->ctx->stream,
+                       e->count, first, count, on, e->flags.p, e->state.p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int klmi_env_sample(klmi_env *e, long n, double *host_out)
+{
+    if (!e)
+        return fail(KLMI_E_ARG, "klmi_env_sample: null envelope");
+    if (n < 0)
+        return fail(KLMI_E_ARG, "Could not cast *bufferSize to size_t!");  // _envelope.c:640-644
+    if (n == 0)
+        return 0;
+    if (!host_out)
+        return fail(KLMI_E_ARG, "klmi_env_sample: null output");
+    TRY(use(e->ctx));
+    const size_t len = (size_t)n * e->count;
+    HIP_TRY(e->out.reserve(len));
+    hipLaunchKernelGGL(env_sample_kernel, dim3((e->count + 63) / 64), dim3(64), 0, e->ctx->stream,
+                       e->count, n, e->coef.p, e->flags.p, e->value.p, e->state.p, e->out.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> t(len);
+    HIP_TRY(hipMemcpyAsync(t.data(), e->out.p, sizeof(double) * len, hipMemcpyDeviceToHost,
+                           e->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    for (int v = 0; v < e->count; ++v)  // [n][count] -> [count][n]
+        for (long i = 0; i < n; ++i)
+            host_out[(size_t)v * n + i] = t[(size_t)i * e->count + v];
+    return 0;
+}
+
+extern "C" int klmi_env_active(klmi_env *e, int32_t *host_out)
+{
+    if (!e || !host_out)
+        return fail(KLMI_E_ARG, "klmi_env_active: null argument");
+    TRY(use(e->ctx));
+    std::vector<uint32_t> raw(e->count);
+    HIP_TRY(hipStreamSynchronize(e->ctx->stream));
+    HIP_TRY(hipMemcpy(raw.data(), e->state.p, sizeof(uint32_t) * e->count, hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->count; ++i)
+        host_out[i] = (raw[i] & 7u) != 0;  // _envelope.c:385-393
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// ring-buffer filter batch
+// ---------------------------------------------------------------------------------
+struct klmi_comb {
+    klmi_ctx *ctx = nullptr;
+    int kind = 0, count = 0, length = 0, position = 0;
+    DevBuf<double> alpha, ring, x, y;
+};
+
+extern "C" int klmi_comb_create(klmi_ctx *ctx, int kind, int count, int length, double alpha,
+                                klmi_comb **out)
+{
+    TRY(use(ctx));
+    if (!out || count <= 0 || kind < 0 || kind > 2)
+        return fail(KLMI_E_ARG, "klmi_comb_create: bad argument");
+    if (length <= 0 || (long)length > 60L * KLMI_SAMPLING_RATE)  // _filters.c:43-46
+        return fail(KLMI_E_MEMORY, "Could not initialize RingBuffer!");
+    klmi_comb *c = new klmi_comb;
+    c->ctx = ctx;
+    c->kind = kind;
+    c->count = count;
+    c->length = length;
+    hipError_t e = c->alpha.alloc(count);
+    if (e == hipSuccess) e = c->ring.alloc((size_t)length * count);
+    if (e == hipSuccess) e = hipMemset(c->ring.p, 0, sizeof(double) * (size_t)length * count);
+    if (e == hipSuccess) {
+        std::vector<double> a(count, alpha);
+        e = hipMemcpy(c->alpha.p, a.data(), sizeof(double) * count, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return fail(KLMI_E_MEMORY, "klmi_comb_create: %s", hipGetErrorString(e));
+    }
+    ctx->live_objects++;
+    *out = c;
+    return 0;
+}
+
+extern "C" int klmi_comb_destroy(klmi_comb *c)
+{
+    if (!c)
+        return 0;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    c->ctx->live_objects--;
+    delete c;
+    return 0;
+}
+
+extern "C" int klmi_comb_set_alpha(klmi_comb *c, int first, int count, const double *host)
+{
+    if (!c || !host || first < 0 || count < 0 || (long)first + count > c->count)
+        return fail(KLMI_E_ARG, "klmi_comb_set_alpha: bad argument");
+    TRY(use(c->ctx));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    HIP_TRY(hipMemcpy(c->alpha.p + first, host, sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int klmi_comb_filter(klmi_comb *c, const double *host_x, long n, double *host_y)
+{
+    if (!c)
+        return fail(KLMI_E_ARG, "klmi_comb_filter: null filter");
+    if (n < 0)
+        return fail(KLMI_E_ARG, "klmi_comb_filter: negative length");
+    if (n == 0)
+        return 0;
+    if (!host_x || !host_y)
+        return fail(KLMI_E_ARG, "klmi_comb_filter: null buffer");
+    TRY(use(c->ctx));
+    const size_t len = (size_t)n * c->count;
+    std::vector<double> t(len);
+    for (int f = 0; f < c->count; ++f)  // [count][n] -> [n][count]
+        for (long i = 0; i < n; ++i)
+            t[(size_t)i * c->count + f] = host_x[(size_t)f * n + i];
+    HIP_TRY(c->x.reserve(len));
+    HIP_TRY(c->y.reserve(len));
+    hipStream_t st = c->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(c->x.p, t.data(), sizeof(double) * len, hipMemcpyHostToDevice, st));
+    const dim3 grid((c->count + 63) / 64), block(64);
+    if (c->kind == 0)
+        hipLaunchKernelGGL(ring_filter_kernel<0>, grid, block, 0, st, c->count, c->length,
+                           c->position, n, c->alpha.p, c->ring.p, c->x.p, c->y.p);
+    else if (c->kind == 1)
+        hipLaunchKernelGGL(ring_filter_kernel<1>, grid, block, 0, st, c->count, c->length,
+                           c->position, n, c->alpha.p, c->ring.p, c->x.p, c->y.p);
+    else
+        hipLaunchKernelGGL(ring_filter_kernel<2>, grid, block, 0, st, c->count, c->length,
+                           c->position, n, c->alpha.p, c->ring.p, c->x.p, c->y.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(t.data(), c->y.p, sizeof(double) * len, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->position = (int)((c->position + n) % c->length);
+    for (int f = 0; f < c->count; ++f)
+        for (long i = 0; i < n; ++i)
+            host_y[(size_t)f * n + i] = t[(size_t)i * c->count + f];
+    return 0;
+}

@@ -1,0 +1,46 @@
+"""Shared builders for the parity tests (test infrastructure)."""
+import numpy as np
+
+from klang_amd import patches as P
+
+B = 256
+
+
+def oracle_bank_from_patch(oracle, patch, table, grid):
+    """OracleBank with the patch's parameters; `table`/`grid` choose whose
+    Butterworth design is used ([rows][5] = b0 b1 b2 a1 a2)."""
+    bank = oracle.OracleBank(patch.n_voices, patch.has_env, patch.has_filter, patch.stereo)
+    bank.wave[:] = patch.wave
+    bank.frequency[:] = patch.frequency
+    bank.set_envelopes(patch.attack, patch.decay, patch.sustain, patch.release, patch.overshoot,
+                       patch.retrigger, patch.loop)
+    bank.coef_table = np.ascontiguousarray(table)
+    bank.coef_index[:] = [oracle.filter_grid_index(grid, c) for c in patch.cutoff]
+    bank.gain[:] = patch.gain
+    pan = np.array([oracle.panning_amplitudes(p) for p in patch.pan])
+    bank.pan_l[:], bank.pan_r[:] = pan[:, 0], pan[:, 1]
+    return bank
+
+
+def hip_bank_from_patch(hip, ctx, patch, **kw):
+    bank = hip.Bank(ctx, patch.n_voices, has_env=patch.has_env, has_filter=patch.has_filter,
+                    stereo=patch.stereo, has_reverb='reverb' in patch,
+                    reverb=patch.get('reverb'), **kw)
+    bank.load_patch(patch)
+    return bank
+
+
+def reference_table(golden):
+    """scipy's own coefficient table from the fixtures, [1000][5]."""
+    g = golden('filter')
+    return np.ascontiguousarray(g['table'][:, [0, 1, 2, 4, 5]]), g['grid']
+
+
+def library_table(hip):
+    """The product's closed-form table, [1000][5] (host-side helpers, no GPU)."""
+    grid = hip.filter_grid()
+    rows = []
+    for f in grid:
+        b, a = hip.butter2_lowpass(f / 22050)
+        rows.append((b[0], b[1], b[2], a[1], a[2]))
+    return np.array(rows), grid
