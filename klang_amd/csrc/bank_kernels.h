@@ -14,7 +14,12 @@
 
 namespace klmi {
 
-__constant__ double c_time[kBlock + 1];  // t[n] = DT * n  (helpers.py:27-32)
+// t[n] = DT * n, n = 0..256 (helpers.py:27-32), padded to whole groups of 8
+constexpr int kTimeSlots = kBlock + 8;
+__constant__ __attribute__((aligned(64))) double c_time[kTimeSlots];
+struct __attribute__((aligned(64))) Time8 {
+    double t[8];
+};
 
 struct BankView {
     int n;  // voices in the bank
@@ -189,53 +194,120 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
 
         const double omega = kTau * freq;  // oscillators.py:60  (TAU * frequency) * t
         const double start = phase;
+        // wave-uniform: may this block use the fast remainder?
+        const bool fast_block =
+            __all(omega >= 0. && start >= 0. && omega * c_time[kBlock] + start < 1e9);
 
         for (int c = 0; c < NCHUNK; ++c) {
             const int s0 = b * kBlock + c * CH;  // sample offset inside this launch
             // One chunk of CH samples.  WK is the wave function when the whole
             // wavefront agrees on it (compile-time dispatch), or -1 (per-lane switch).
-            auto run_chunk = [&](auto wk) {
+            // FAST: every lane's phase argument of this block is >= 0 and < 1e9, so
+            // the remainder needs no sign handling and no library fallback.
+            auto run_chunk = [&](auto wk, auto fast) {
                 constexpr int WK = decltype(wk)::value;
-#pragma unroll 8
-                for (int i = 0; i < CH; ++i) {
-                    const int n = c * CH + i;
+                constexpr bool FAST = decltype(fast)::value;
+                for (int i8 = 0; i8 < CH; i8 += 8) {
+                    // 8 time points per scalar load (wave-uniform index)
+                    const Time8 tt = reinterpret_cast<const Time8 *>(c_time)[(c * CH + i8) >> 3];
                     const int wsel = (WK >= 0) ? WK : wave_id;
-                    double x;
-                    if (wsel == W_EXTERNAL) {
-                        x = bk.ext_input[(size_t)(block_base * kBlock + s0 + i) * bk.n + v];
-                    } else if (wsel == W_ONE) {
-                        x = 1.;
-                    } else {
-                        const double p = np_mod_tau(omega * c_time[n] + start);
-                        x = wave_eval(wsel, p, duty_edge);
-                    }
-                    if (ENV) {
-                        const double e = es.step(ep);
-                        x = amp * x * e;  // voices.py:73  (amplitude * osc) * env
-                    }
-                    if (FILT)
-                        x = bq.step(x);
+                    double xs[8];
 
-                    if constexpr (MODE == OUT_MIX_MONO) {
-                        tile[i * TT::stride + lane] = (float)(gl * x);
-                    } else if constexpr (MODE == OUT_MIX_STEREO) {
-                        tile[i * TT::stride + lane] = (float)(gl * x);
-                        tile[(CH + i) * TT::stride + lane] = (float)(gr * x);
-                    } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
-                        tile[i * TT::stride + lane] = (T)x;
+                    // -- oscillator: 8 independent samples, straight-line -------------
+                    if (wsel == W_EXTERNAL) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            xs[j] = bk.ext_input[(size_t)(block_base * kBlock + s0 + i8 + j) * bk.n + v];
+                    } else if (wsel == W_ONE) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            xs[j] = 1.;
                     } else {
-                        if (live)
-                            reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
+                        double ph[8];
+                        if constexpr (FAST) {
+                            // remainder without repair; one wave-level branch per 8
+                            // samples redoes them exactly if any lane needs the repair
+                            double arg[8];
+                            bool bad = false;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                arg[j] = omega * tt.t[j] + start;
+                                const double k = floor(arg[j] * kInvTau);
+                                ph[j] = __builtin_fma(-k, kTau, arg[j]);
+                                bad |= !(ph[j] >= 0. && ph[j] < kTau);
+                            }
+                            if (__any(bad)) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    ph[j] = fmod_tau_fast(arg[j]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                ph[j] = np_mod_tau(omega * tt.t[j] + start);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            xs[j] = wave_eval(wsel, ph[j], duty_edge);
+                    }
+
+                    // -- envelope: speculate "no stage switch in these 8 samples" ------
+                    if (ENV) {
+                        double e[8];
+                        double vv = es.value;
+                        bool hit = false;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            vv = es.base + vv * es.coef;
+                            hit |= es.rising ? (vv >= es.limit) : (vv <= es.limit);
+                            e[j] = vv;
+                        }
+                        if (__any(hit)) {  // rare: exact state machine for the whole wave
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                e[j] = es.step(ep);
+                        } else {
+                            es.value = vv;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            xs[j] = amp * xs[j] * e[j];  // voices.py:73 (amplitude * osc) * env
+                    }
+
+                    // -- biquad (serial) and output -----------------------------------------
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int i = i8 + j;
+                        double x = xs[j];
+                        if (FILT)
+                            x = bq.step(x);
+                        if constexpr (MODE == OUT_MIX_MONO) {
+                            tile[i * TT::stride + lane] = (float)(gl * x);
+                        } else if constexpr (MODE == OUT_MIX_STEREO) {
+                            tile[i * TT::stride + lane] = (float)(gl * x);
+                            tile[(CH + i) * TT::stride + lane] = (float)(gr * x);
+                        } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
+                            tile[i * TT::stride + lane] = (T)x;
+                        } else {
+                            if (live)
+                                reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
+                        }
                     }
                 }
             };
-            switch (uniform_wave) {
-            case W_SINE: run_chunk(std::integral_constant<int, W_SINE>{}); break;
-            case W_SQUARE: run_chunk(std::integral_constant<int, W_SQUARE>{}); break;
-            case W_SAWTOOTH: run_chunk(std::integral_constant<int, W_SAWTOOTH>{}); break;
-            case W_TRIANGLE: run_chunk(std::integral_constant<int, W_TRIANGLE>{}); break;
-            case W_PWM: run_chunk(std::integral_constant<int, W_PWM>{}); break;
-            default: run_chunk(std::integral_constant<int, -1>{}); break;
+            using std::integral_constant;
+            using Fast = std::true_type;
+            if (fast_block) {
+                switch (uniform_wave) {
+                case W_SINE: run_chunk(integral_constant<int, W_SINE>{}, Fast{}); break;
+                case W_SQUARE: run_chunk(integral_constant<int, W_SQUARE>{}, Fast{}); break;
+                case W_SAWTOOTH: run_chunk(integral_constant<int, W_SAWTOOTH>{}, Fast{}); break;
+                case W_TRIANGLE: run_chunk(integral_constant<int, W_TRIANGLE>{}, Fast{}); break;
+                case W_PWM: run_chunk(integral_constant<int, W_PWM>{}, Fast{}); break;
+                default: run_chunk(integral_constant<int, -1>{}, Fast{}); break;
+                }
+            } else {
+                run_chunk(integral_constant<int, -1>{}, std::false_type{});
             }
             // the tile is wave-private: LDS operations of one wave execute in order;
             // the fence only stops the compiler from moving them across this point

@@ -37,6 +37,17 @@ __device__ __forceinline__ double fmod_tau_nonneg(double x)
     return r;
 }
 
+// The same for 0 <= x < 1e9 (checked per block by the caller): no early-outs, the
+// off-by-one repair is one rarely taken branch.
+__device__ __forceinline__ double fmod_tau_fast(double x)
+{
+    const double k = floor(x * kInvTau);
+    double r = __builtin_fma(-k, kTau, x);
+    if (__builtin_expect(r < 0. || r >= kTau, 0))
+        r = __builtin_fma(-(r < 0. ? k - 1. : k + 1.), kTau, x);
+    return r;
+}
+
 // np.mod(x, TAU) (oscillators.py:66): C fmod, then the divisor's sign.
 __device__ __forceinline__ double np_mod_tau(double x)
 {

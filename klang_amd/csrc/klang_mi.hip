@@ -240,8 +240,8 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         double *row = &ctx->table[(size_t)i * 5];
         row[0] = b[0], row[1] = b[1], row[2] = b[2], row[3] = a[1], row[4] = a[2];
     }
-    double t[kBlock + 1];
-    for (int n = 0; n <= kBlock; ++n)
+    double t[kTimeSlots];
+    for (int n = 0; n < kTimeSlots; ++n)
         t[n] = kDt * (double)n;  // helpers.py:30  dt * np.arange(length)
     hipError_t e = ctx->d_table.alloc(ctx->table.size());
     if (e == hipSuccess)
