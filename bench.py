@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VOICES_PER_GPU = 65536
+VOICES_PER_GPU = int(os.environ.get('KLANG_BENCH_VOICES', '65536'))  # override: experiments only
 BLOCKS_PER_STEP = 512
 B = 256
 # params 80 B + 2 x state 36 B per voice per 256-sample block, + 4 B/N bus

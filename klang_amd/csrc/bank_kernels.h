@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                                 arg[j] = omega * tt.t[j] + start;
                                 const double k = floor(arg[j] * kInvTau);
                                 ph[j] = __builtin_fma(-k, kTau, arg[j]);
-                                bad |= !(ph[j] >= 0. && ph[j] < kTau);
+                                bad |= !in_zero_tau(ph[j]);
                             }
                             if (__any(bad)) {
 #pragma unroll
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                         }
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            xs[j] = wave_eval(wsel, ph[j], duty_edge);
+                            xs[j] = wave_eval<FAST>(wsel, ph[j], duty_edge);
                     }
 
                     // -- envelope: speculate "no stage switch in these 8 samples" ------

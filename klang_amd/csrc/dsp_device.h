@@ -96,7 +96,28 @@ __device__ __forceinline__ double div_tau(double a)
     return __builtin_fma(r, kInvTau, q);
 }
 
+// (2 a) / TAU, correctly rounded, without forming 2a: scaling by two is exact,
+// so this is div_tau(2 a) with every operand halved or doubled accordingly.
+__device__ __forceinline__ double div_pi(double a)
+{
+    constexpr double kInvPi = 2. * kInvTau;
+    const double q = a * kInvPi;
+    const double r = __builtin_fma(-q, kPi, a);
+    return __builtin_fma(r, kInvPi, q);
+}
+
+// 0 <= p < TAU as ONE integer compare: non-negative doubles order like their
+// bit patterns, and any set sign bit (negative values, -0.0) compares high.
+__device__ __forceinline__ bool in_zero_tau(double p)
+{
+    return (unsigned long long)__double_as_longlong(p) <
+           (unsigned long long)__double_as_longlong(kTau);
+}
+
 // waves.py:22-39 / oscillators.py:259-260.  `p` is the wrapped phase.
+// WRAPPED: the caller guarantees 0 <= p < TAU (the np.mod(phase, TAU) of
+// waves.py:34 is then the identity).
+template <bool WRAPPED = false>
 __device__ __forceinline__ double wave_eval(int wave, double p, double duty_edge)
 {
     switch (wave) {
@@ -105,8 +126,8 @@ __device__ __forceinline__ double wave_eval(int wave, double p, double duty_edge
     case W_SQUARE:
         return (wrap_shifted(p) - kPi >= 0.) ? 1. : -1.;
     case W_SAWTOOTH: {
-        const double m = p >= kTau ? p - kTau : p;  // np.mod(phase, TAU), waves.py:34
-        return div_tau(2. * m) - 1.;
+        const double m = (!WRAPPED && p >= kTau) ? p - kTau : p;  // np.mod(phase, TAU)
+        return div_pi(m) - 1.;   // 2. * m / TAU - 1.
     }
     case W_TRIANGLE: {
         const double w = wrap_shifted(p) - kPi;
@@ -194,14 +215,20 @@ struct EnvState {
 
 // scipy.signal.lfilter, order 2, a0 == 1 (effects.py:309-316): direct form II
 // transposed, y = z0 + b0 x; z0 = z1 + b1 x - a1 y; z1 = b2 x - a2 y.
+// The Butterworth low-pass numerator is b0 * [1, 2, 1] with b1 == 2 b0 and
+// b2 == b0 exactly (scipy's zpk2tf and the closed form both produce it; the
+// host checks the table).  Doubling is exact, so b1*x == 2*(b0*x) and
+// z1 + b1*x == fma(2, b0*x, z1) bit for bit (outside the subnormal range, where
+// results may differ by one unit of 2^-1074): 7 operations instead of 9.
 struct Biquad {
     double b0, b1, b2, a1, a2;
     double z0, z1;
     __device__ __forceinline__ double step(double x)
     {
-        const double y = z0 + b0 * x;
-        z0 = z1 + b1 * x - a1 * y;
-        z1 = b2 * x - a2 * y;
+        const double t = b0 * x;
+        const double y = z0 + t;
+        z0 = __builtin_fma(2., t, z1) - a1 * y;
+        z1 = t - a2 * y;
         return y;
     }
 };

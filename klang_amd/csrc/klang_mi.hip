@@ -239,6 +239,10 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         butter2(ctx->grid[i] / (KLMI_SAMPLING_RATE / 2), b, a);  // helpers.py:15 NYQUIST (int)
         double *row = &ctx->table[(size_t)i * 5];
         row[0] = b[0], row[1] = b[1], row[2] = b[2], row[3] = a[1], row[4] = a[2];
+        if (b[1] != 2. * b[0] || b[2] != b[0]) {  // the kernel's biquad relies on it
+            delete ctx;
+            return fail(KLMI_E_STATE, "filter table row %d is not b0*[1,2,1]", i);
+        }
     }
     double t[kTimeSlots];
     for (int n = 0; n < kTimeSlots; ++n)
