@@ -1,0 +1,297 @@
+"""Graph compiler: hands oscillator -> envelope -> filter -> reverb -> mixer
+chains of a patch to the HIP library.
+
+The execution order stays the one derived from the DAG (klang_amd/schedule.py,
+klang/execution.py:37-58 in the reference).  In that order every ``Mixer`` /
+``StereoMixer`` whose inputs are all *voice chains* of one shape
+
+    Voice(Oscillator|PwmOscillator, ADSR|AR|D|R)  or a bare oscillator
+        [ | Filter ]  [ | Reverb ]   ->  mixer input
+
+is replaced, together with the chain blocks, by one ``GpuVoiceBank`` block that
+owns a device-resident ``klang_amd.native.Bank`` (one voice per mixer input).
+Chains that end anywhere else (``Oscillator(440.) | Dac()``) become one-voice
+banks.  Per buffer the bank block drains the voices' note queues into
+block-boundary events (voices.py:55-64), renders, and publishes the mix on the
+mixer's own ``Output`` object, so downstream connections are untouched.
+
+There is no fallback: under ``backend='hip'`` a hot-path block that cannot be
+fused is an error, and a missing library or GPU raises from klang_amd.native.
+"""
+from fractions import Fraction
+
+import numpy as np
+
+from klang_amd import native
+from klang_amd.audio.envelopes import EnvelopeBase
+from klang_amd.audio.filtering import BackwardCombFilter, Filter, Reverb
+from klang_amd.audio.mixers import Mixer, StereoMixer
+from klang_amd.audio.signals import Lfo, Oscillator, Phasor, PwmOscillator, WAVE_IDS
+from klang_amd.audio.voices import Voice
+from klang_amd.block import Block
+from klang_amd.composite import Composite
+from klang_amd.errors import KlangError
+from klang_amd.tempo import compute_rate
+
+HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer)
+
+
+class NotFusable(KlangError):
+    """Why a chain cannot be handed to the device (message says which rule)."""
+
+
+class Chain:
+    """One voice chain, source first: oscillator [+ envelope via Voice]
+    [-> Filter] [-> Reverb]; `end` is the block whose output leaves the chain."""
+
+    def __init__(self, end):
+        self.end = end
+        self.blocks = []
+        self.voice = self.oscillator = self.envelope = self.filter = self.reverb = None
+        self._walk(end)
+
+    def _walk(self, block):
+        stage = block
+        if isinstance(stage, Reverb):
+            if stage.echoType is not BackwardCombFilter:
+                raise NotFusable('%s: only BackwardCombFilter echoes run on the device' % stage)
+            self.reverb, stage = stage, self._upstream(stage)
+        if isinstance(stage, Filter):
+            if stage.frequency.connected:
+                raise NotFusable('%s: modulated cutoff inputs are not fused yet' % stage)
+            self.filter, stage = stage, self._upstream(stage)
+        if isinstance(stage, Voice):
+            self.voice = stage
+            self.oscillator, self.envelope = stage.oscillator, stage.envelope
+            if not isinstance(self.envelope, EnvelopeBase):
+                raise NotFusable('%s: envelope type %s' % (stage, type(self.envelope).__name__))
+            for inner in (self.oscillator, self.envelope):
+                if any(o.connected for o in inner.outputs):
+                    raise NotFusable('%s: inner block %s is patched elsewhere' % (stage, inner))
+        else:
+            self.oscillator = stage
+        osc = self.oscillator
+        if type(osc) not in (Oscillator, PwmOscillator):
+            raise NotFusable('%s is not an oscillator the device evaluates' % osc)
+        if type(osc) is Oscillator and osc.wave_func not in WAVE_IDS:
+            raise NotFusable('%s: wave function %r has no device twin' % (osc, osc.wave_func))
+        if any(i.connected for i in osc.inputs):
+            raise NotFusable('%s: modulated oscillator inputs are not fused yet' % osc)
+        if np.ndim(osc.frequency.value) != 0:
+            raise NotFusable('%s: array-rate frequency is not fused yet' % osc)
+        self.blocks = [b for b in (self.voice or self.oscillator, self.filter, self.reverb) if b]
+
+    @staticmethod
+    def _upstream(block):
+        src = block.input.incomingConnection
+        if src is None or src.owner is None:
+            raise NotFusable('%s has no upstream block' % block)
+        if len(src.outgoingConnections) != 1:
+            raise NotFusable('%s feeds more than one input' % src.owner)
+        return src.owner
+
+    @property
+    def shape(self):
+        rv = self.reverb
+        return (self.voice is not None, self.filter is not None,
+                (rv.decay, rv.preDelay, rv.dryWet, rv.nEchos) if rv else None)
+
+    def wave_id(self):
+        if isinstance(self.oscillator, PwmOscillator):
+            return native.WAVE_PWM
+        return WAVE_IDS[self.oscillator.wave_func]
+
+
+class GpuVoiceBank(Block):
+    """A fused set of chains evaluated by one device bank.  `sink` is the block
+    whose output carries the result (the mixer, or the chain end itself)."""
+
+    def __init__(self, chains, sink, ctx=None):
+        super().__init__()
+        self.chains, self.sink = chains, sink
+        self.ctx = ctx or native.default_context()
+        has_env, has_filter, reverb = chains[0].shape
+        self.stereo = isinstance(sink, StereoMixer)
+        self.is_mixer = isinstance(sink, Mixer)
+        kw = {}
+        if self.stereo:
+            kw = dict(pan_mode=sink.mode, pan_law=sink.panLaw)
+        self.bank = native.Bank(
+            self.ctx, len(chains), has_env=has_env, has_filter=has_filter,
+            has_reverb=reverb is not None, stereo=self.stereo,
+            reverb=dict(zip(('decay', 'pre_delay', 'dry_wet', 'n_echos'), reverb)) if reverb else None,
+            **kw)
+        self.lookahead = 1      # blocks rendered per device call (set by run_klang)
+        self._ready = []
+        self._upload()
+
+    # -- parameters / state ------------------------------------------------------------
+    def _upload(self):
+        F, bank, ch = native, self.bank, self.chains
+        oscs = [c.oscillator for c in ch]
+        bank.set(F.F_WAVE, [c.wave_id() for c in ch])
+        bank.set(F.F_FREQUENCY, [float(compute_rate(o.frequency.value)) for o in oscs])
+        bank.set(F.F_DUTY, [float(o.dutyCycle.value) if isinstance(o, PwmOscillator) else .5
+                            for o in oscs])
+        bank.set_state(F.F_PHASE, [float(o.currentPhase) for o in oscs])
+        if ch[0].voice is not None:
+            envs = [c.envelope for c in ch]
+            for field, name in ((F.F_ATTACK, 'attack'), (F.F_DECAY, 'decay'),
+                                (F.F_SUSTAIN, 'sustain'), (F.F_RELEASE, 'release'),
+                                (F.F_OVERSHOOT, 'overshoot'), (F.F_LOOP, 'loop'),
+                                (F.F_RETRIGGER, 'retrigger')):
+                bank.set(field, [float(getattr(e, name)) for e in envs])
+            bank.set(F.F_AMPLITUDE, [float(c.voice.amplitude) for c in ch])
+            bank.set_state(F.F_ENV_VALUE, [e.value for e in envs])
+            bank.set_state(F.F_ENV_STAGE, [e.stage for e in envs])
+            bank.set_state(F.F_ENV_ENABLED, [float(e.enabled) for e in envs])
+        if ch[0].filter is not None:
+            bank.set(F.F_CUTOFF, [float(c.filter.frequency.value) for c in ch])
+            self._cutoffs = [c.filter.frequency.value for c in ch]
+        if self.is_mixer:
+            bank.set(F.F_GAIN, [float(g) for g in self.sink.gains])
+            if self.stereo:
+                bank.set(F.F_PAN, [float(p) for p in self.sink.pannings])
+            self._gains = list(self.sink.gains)
+            self._pans = list(getattr(self.sink, 'pannings', []))
+
+    def _collect_events(self):
+        """Voice.process_incoming_notes (voices.py:55-64) for every voice, plus
+        parameter edits made on the host blocks since the last buffer."""
+        F, bank = native, self.bank
+        for i, c in enumerate(self.chains):
+            if c.voice is not None:
+                for note in c.voice.input.receive():
+                    if note.on:
+                        bank.event(i, 0, F.EV_NOTE_ON, note.velocity, note.frequency)
+                        c.voice.amplitude = note.velocity
+                        c.voice.currentPitch = note.pitch
+                        c.oscillator.frequency.set_value(note.frequency)
+                    else:
+                        bank.event(i, 0, F.EV_NOTE_OFF)
+                        c.voice.currentPitch = 0
+                for note in c.envelope.input.receive():        # envelopes.py:40-42
+                    bank.event(i, 0, F.EV_NOTE_ON if note.on else F.EV_NOTE_OFF,
+                               c.voice.amplitude, float(compute_rate(c.oscillator.frequency.value)))
+            if c.filter is not None and c.filter.frequency.value != self._cutoffs[i]:
+                self._cutoffs[i] = c.filter.frequency.value
+                bank.event(i, 0, F.EV_SET_CUTOFF, 0., float(self._cutoffs[i]))
+        if self.is_mixer:
+            if list(self.sink.gains) != self._gains:
+                self._gains = list(self.sink.gains)
+                bank.set(F.F_GAIN, [float(g) for g in self._gains])
+            if self.stereo and list(self.sink.pannings) != self._pans:
+                self._pans = list(self.sink.pannings)
+                bank.set(F.F_PAN, [float(p) for p in self._pans])
+
+    @property
+    def pending_messages(self):
+        return any(c.voice is not None and (c.voice.input.queue or c.envelope.input.queue)
+                   for c in self.chains)
+
+    def update(self):
+        if self._ready and self.pending_messages:
+            raise KlangError('GpuVoiceBank: notes arrived while buffers were rendered ahead; '
+                             'use lookahead=1 for patches with live message sources')
+        if not self._ready:
+            self._collect_events()
+            # float32 [n][channels][256] -> per buffer (256,) mono or (2, 256) stereo
+            mix = self.bank.render(max(1, int(self.lookahead)))
+            self._ready = [blk if self.stereo else blk[0] for blk in mix][::-1]
+        self.sink.output.set_value(self._ready.pop().astype(np.float64))
+
+    def sync_host_blocks(self):
+        """Copy device state back into the host blocks (currentPhase, envelope
+        stage/value) so that the patch can be inspected or re-run on the host."""
+        F, bank = native, self.bank
+        phase = bank.get_state(F.F_PHASE)
+        for i, c in enumerate(self.chains):
+            c.oscillator.currentPhase = float(phase[i])
+        if self.chains[0].voice is not None:
+            value, stage = bank.get_state(F.F_ENV_VALUE), bank.get_state(F.F_ENV_STAGE)
+            enabled = bank.get_state(F.F_ENV_ENABLED)
+            for i, c in enumerate(self.chains):
+                c.envelope.value, c.envelope.stage = float(value[i]), int(stage[i])
+                c.envelope.enabled = bool(enabled[i])
+
+    def close(self):
+        self.bank.close()
+
+    def __str__(self):
+        return 'GpuVoiceBank(%d voices -> %s)' % (len(self.chains), type(self.sink).__name__)
+
+
+def _flat(order):
+    for blk in order:
+        yield blk
+        if isinstance(blk, Composite):
+            yield from _flat(blk.execOrder)
+
+
+def find_fusable(exec_order):
+    """-> (groups, errors): groups = [(sink, [Chain, ...])] for every mixer whose
+    inputs are uniform chains and for every other chain end; errors = reasons
+    for hot-path blocks that stay outside."""
+    groups, errors, claimed = [], [], set()
+    for blk in exec_order:
+        if isinstance(blk, Mixer) and blk.nInputs > 0:
+            try:
+                chains = []
+                for inp in blk.inputs:
+                    src = inp.incomingConnection
+                    if src is None or src.owner is None:
+                        raise NotFusable('%s has an unconnected input' % blk)
+                    if len(src.outgoingConnections) != 1:
+                        raise NotFusable('%s feeds more than one input' % src.owner)
+                    chains.append(Chain(src.owner))
+                if len({c.shape for c in chains}) != 1:
+                    raise NotFusable('%s mixes chains of different shapes' % blk)
+                groups.append((blk, chains))
+                claimed.update(b for c in chains for b in c.blocks)
+                claimed.add(blk)
+            except NotFusable as err:
+                errors.append(str(err))
+    # chain ends that feed something other than a fused mixer
+    for blk in exec_order:
+        if blk in claimed or not isinstance(blk, (Phasor, Voice, Filter, Reverb)):
+            continue
+        if type(blk) in (Phasor, Lfo):
+            continue   # control-rate sources stay on the host
+        consumers = [d.owner for o in blk.outputs for d in o.outgoingConnections]
+        if any(isinstance(c, (Filter, Reverb)) and c not in claimed for c in consumers):
+            continue   # not the end of its chain
+        try:
+            chain = Chain(blk)
+            groups.append((blk, [chain]))
+            claimed.update(chain.blocks)
+        except NotFusable as err:
+            errors.append(str(err))
+    return groups, errors
+
+
+def compile_order(exec_order, ctx=None, strict=True):
+    """Replace fusable chains in `exec_order` by GpuVoiceBank blocks.  With
+    strict=True every hot-path block must end up fused (KlangError otherwise)."""
+    groups, errors = find_fusable(exec_order)
+    fused_blocks, banks_at = set(), {}
+    for sink, chains in groups:
+        bank = GpuVoiceBank(chains, sink, ctx)
+        for c in chains:
+            fused_blocks.update(c.blocks)
+        fused_blocks.add(sink)
+        banks_at[sink] = bank
+    new_order = []
+    for blk in exec_order:
+        if blk in banks_at:
+            new_order.append(banks_at[blk])
+        elif blk not in fused_blocks:
+            new_order.append(blk)
+    if strict:
+        left = [b for b in _flat(new_order) if isinstance(b, HOT_PATH_TYPES)
+                and type(b) not in (Phasor, Lfo)]
+        if left:
+            raise KlangError(
+                "backend='hip': %d hot-path block(s) could not be handed to the device (%s). %s "
+                "Use backend='host' explicitly to evaluate the patch with the NumPy host blocks."
+                % (len(left), ', '.join(str(b) for b in left[:4]), ' / '.join(errors[:4])))
+    return new_order, list(banks_at.values())

@@ -1,0 +1,73 @@
+"""Entry point: ``run_klang(*blocks, filepath=..., offline=True, duration=...)``
+(klang/klang.py:16-90).
+
+``backend='hip'`` (default) compiles the execution order with
+klang_amd.fusion so that the DSP hot path runs in the HIP library; it raises if
+the library or a GPU is missing, or if a hot-path block cannot be fused --
+never a silent CPU evaluation.  ``backend='host'`` is the explicit NumPy
+evaluation of the same blocks (plumbing / reference behaviour, no GPU).
+"""
+import collections
+import logging
+
+from klang_amd.audio.engine import Adc, Dac, look_for_audio_blocks, run_audio_engine  # noqa: F401
+from klang_amd.composite import Composite
+from klang_amd.errors import KlangError
+from klang_amd.schedule import determine_execution_order
+
+BACKENDS = ('hip', 'host')
+
+
+def unravel(execOrder):
+    """Flatten composites into their internal order (klang.py:16-24)."""
+    for block in execOrder:
+        if isinstance(block, Composite):
+            yield from unravel(block.execOrder)
+        else:
+            yield block
+
+
+def validate_global_execution_order(execOrder, logger):
+    """Warn about blocks that would run more than once per buffer (klang.py:27-48)."""
+    counts = collections.Counter(unravel(execOrder))
+    dup = ['  - %s: %dx' % (b, n) for b, n in counts.items() if n > 1]
+    if dup:
+        logger.warning('Found duplicates in flattened execOrder! Following blocks will get '
+                       'executed multiple times per buffer cycle!\n%s', '\n'.join(dup))
+
+
+def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
+    """Run a block network.  kwargs: duration, fadeout, filepath, offline (see
+    klang_amd.audio.engine.run_audio_engine).  Returns the list of rendered
+    float32 buffers (BUFFER_SIZE, nChannels)."""
+    if not blocks:
+        raise ValueError('No blocks to run specified!')
+    if backend not in BACKENDS:
+        raise ValueError('backend must be one of %s' % (BACKENDS,))
+    logger = logging.getLogger('Klang')
+    execOrder = determine_execution_order(blocks)
+    validate_global_execution_order(execOrder, logger)
+    adc, dac = look_for_audio_blocks(execOrder)
+    if adc.nChannels == 0 and dac.nChannels == 0:
+        raise KlangError('Did not find any audio activity (no Adc / Dac in the patch)')
+
+    banks = []
+    if backend == 'hip':
+        from klang_amd import fusion
+        execOrder, banks = fusion.compile_order(execOrder, strict=True)
+        # rendering ahead is safe when nothing on the host can emit a note between buffers
+        only_io = all(isinstance(b, (fusion.GpuVoiceBank, Adc, Dac)) for b in execOrder)
+        ahead = (64 if only_io else 1) if lookahead is None else int(lookahead)
+        for bank in banks:
+            bank.lookahead = ahead
+
+    def execute_all_blocks():
+        for block in execOrder:
+            block.update()
+
+    try:
+        return run_audio_engine(adc, dac, execute_all_blocks, **kwargs)
+    finally:
+        for bank in banks:
+            bank.sync_host_blocks()
+            bank.close()

@@ -1,0 +1,126 @@
+"""run_klang(backend='hip'): patches written against the Block / | / + API are
+compiled into device banks and must reproduce the reference fixtures."""
+import wave
+
+import numpy as np
+import pytest
+
+from klang_amd import fusion, patches as P
+from klang_amd.audio import (ADSR, AR, Dac, Filter, Mixer, Oscillator, Reverb, StereoMixer,
+                             Voice, sawtooth, sine)
+from klang_amd.errors import KlangError
+from klang_amd.klang import run_klang
+from klang_amd.messages import Note
+from klang_amd.schedule import determine_execution_order
+
+pytestmark = pytest.mark.gpu
+B = 256
+
+
+def test_hello_world_through_the_device(hip, tmp_path, golden):
+    path = str(tmp_path / 'hello.wav')
+    osc = Oscillator(frequency=440.)
+    frames = run_klang(osc | Dac(), filepath=path, offline=True, duration=1.0)
+    audio = np.concatenate(frames)
+    assert audio.shape == (172 * B, 1)
+    np.testing.assert_allclose(audio[:4 * B, 0].reshape(4, B),
+                               golden('hello_world')['first_blocks_f32'], rtol=0, atol=6e-8)
+    with wave.open(path, 'rb') as wav:
+        assert wav.getnframes() == 44032
+    # device state was copied back into the host block
+    t = 172 * B / 44100.
+    assert abs(osc.currentPhase - (2 * np.pi * 440. * t) % (2 * np.pi)) < 1e-6
+
+
+def test_haunting_envelopes_patch_through_the_api(hip, golden):
+    """examples/haunting_envelopes.py:75-92 rewritten against klang_amd: 20 looping
+    AR voices into a StereoMixer into a stereo Dac."""
+    g = golden('chains')
+    p = P.haunting_patch()
+    mixer = StereoMixer()
+    for v in range(20):
+        voice = Voice(Oscillator(wave_func=sine), AR(p.attack[v], p.release[v], loop=True))
+        mixer += voice
+        mixer.pannings[-1] = p.pan[v]
+        voice.input.push(Note(0, p.velocity[v], frequency=p.frequency[v]))
+    dac = mixer | Dac(nChannels=2)
+    frames = run_klang(dac, offline=True, duration=130 * B / 44100. + 1e-9)
+    audio = np.stack(frames)                    # [blocks][256][2]
+    kept = [b for b in g['config2_kept_blocks'] if b < len(frames)]
+    want = g['config2_mix'][:len(kept)]         # [k][2][256]
+    got = audio[kept].transpose(0, 2, 1)
+    assert len(kept) >= 6 and np.abs(got - want).max() <= 1e-6
+
+
+def test_voice_filter_mixer_patch_with_live_notes(hip, golden):
+    """Config-3 mini-patch through the API with notes pushed between buffers
+    (lookahead 1): the compiled order has one bank and no host DSP block."""
+    g = golden('chains')
+    p = P.polyphonic_saw_patch(n_voices=48, n_blocks=40, off_base=6, off_span=12)
+    mixer, voices = Mixer(), []
+    for v in range(48):
+        voice = Voice(Oscillator(wave_func=sawtooth),
+                      ADSR(p.attack[v], p.decay[v], p.sustain[v], p.release[v]))
+        fil = Filter(frequency=p.cutoff[v])
+        voice | fil
+        mixer += fil
+        voices.append(voice)
+    dac = mixer | Dac()
+    order, banks = fusion.compile_order(determine_execution_order([dac]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac'] and len(banks) == 1
+    by_block = {}
+    for ev in p.events:
+        note = Note(0, float(ev['velocity']) if ev['kind'] == 1 else 0., float(ev['frequency']))
+        by_block.setdefault(int(ev['block']), []).append((int(ev['voice']), note))
+    out = []
+    for b in range(40):
+        for v, note in by_block.get(b, ()):
+            voices[v].input.push(note)
+        for blk in order:
+            blk.update()
+        out.append(mixer.output.value)
+    assert np.abs(np.array(out) - g['config3_mini_mix']).max() <= 1e-6
+    banks[0].sync_host_blocks()
+    np.testing.assert_array_equal([v.oscillator.currentPhase for v in voices],
+                                  g['config3_mini_final_phase'])
+    banks[0].close()
+
+
+def test_reverb_chain_and_parameter_edits(hip, oracle):
+    voice = Voice(Oscillator(), AR(.01, .2))
+    rv = Reverb(decay=3., dryWet=.7)
+    mixer = Mixer()
+    voice | rv
+    mixer += rv
+    dac = mixer | Dac()
+    order, banks = fusion.compile_order(determine_execution_order([dac]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac']
+    voice.input.push(Note(69, 1.))
+    out = []
+    for b in range(12):
+        if b == 6:
+            mixer.gains[0] = .5                 # host-side edit is picked up
+        for blk in order:
+            blk.update()
+        out.append(mixer.output.value)
+    out = np.concatenate(out)
+    bank = oracle.OracleBank(1, True, False, False)
+    bank.wave[:] = 0
+    bank.set_envelope(0, .01, 0., 1., .2)
+    ev = P.make_events(0, 0, P.EV_NOTE_ON, 1., 440.)
+    _, dry = bank.render(12, ev, want_voices=True)
+    r = oracle.OracleReverb(decay=3., dry_wet=.7)
+    want = np.concatenate([r.run(dry[0, b * B:(b + 1) * B]) for b in range(12)])
+    want[6 * B:] *= .5
+    assert np.abs(out - want).max() <= 1e-6
+    banks[0].close()
+
+
+def test_strict_backend_refuses_unfusable_hot_path_blocks(hip):
+    from klang_amd.audio import Lfo
+    lfo = Lfo(frequency=2., outputRange=(200., 2000.))
+    osc, fil = Oscillator(wave_func=sawtooth), Filter()
+    lfo | fil.frequency
+    with pytest.raises(KlangError) as e:
+        run_klang(osc | fil | Dac(), offline=True, duration=.1)
+    assert "backend='hip'" in str(e.value) and 'modulated cutoff' in str(e.value)

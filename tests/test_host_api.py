@@ -1,0 +1,213 @@
+"""Host-side mirror of the reference's Block / connection / scheduler API.
+Expectations restate the reference's own unit tests (tests/test_block.py,
+test_connections.py, test_graph.py:140-243, test_execution.py, test_composite.py,
+test_audio_mixer.py, test_audio_voices.py there); nothing here needs a GPU."""
+import numpy as np
+import pytest
+
+from klang_amd.audio import (ADSR, AR, Dac, Mixer, Oscillator, StereoMixer, Voice, sawtooth)
+from klang_amd.block import Block, fetch_input, fetch_output
+from klang_amd.composite import Composite, temporarily_unpatch
+from klang_amd.messages import Note
+from klang_amd.schedule import determine_execution_order, find_back_edges, topological_order
+from klang_amd.wiring import (IncompatibleConnection, Input, InputAlreadyConnected,
+                              MessageInput, MessageOutput, MessageRelay, Output, Relay,
+                              are_connected, is_connected)
+
+
+def connected(a, b):
+    out, inp = fetch_output(a), fetch_input(b)
+    return out is inp.incomingConnection and inp in out.outgoingConnections
+
+
+# ---- connections -------------------------------------------------------------------
+def test_connect_disconnect_and_one_to_many():
+    src, a, b = Output(), Input(), Input()
+    src.connect(a)
+    b.connect(src)
+    assert is_connected(src, a) and is_connected(src, b) and src.connected
+    with pytest.raises(InputAlreadyConnected):
+        Output().connect(a)
+    src.disconnect(a)
+    assert not a.connected and not is_connected(src, a)
+    with pytest.raises(IncompatibleConnection):
+        MessageOutput().connect(Input())
+    with pytest.raises(IncompatibleConnection):
+        Output().connect(MessageInput())
+    assert not is_connected(Output(), MessageInput())
+
+
+def test_value_flow_through_relays():
+    src, r1, r2, dst = Output(), Relay(), Relay(), Input(value=7.)
+    assert dst.value == 7.
+    src.connect(r1)
+    r1.connect(r2)
+    r2.connect(dst)
+    assert are_connected(src, r1, r2, dst)
+    src.set_value('payload')
+    assert dst.value == 'payload' and dst.get_value() == 'payload'
+    r2.disconnect(dst)
+    assert dst.value == 7.
+
+
+def test_message_flow_and_queue_semantics():
+    src, relay, a, b = MessageOutput(), MessageRelay(), MessageInput(), MessageInput()
+    src.connect(relay)
+    relay.connect(a)
+    src.connect(b)
+    for i in range(3):
+        src.send(i)
+    assert list(a.receive()) == [0, 1, 2] and not a.queue
+    assert b.receive_latest() == 2 and not b.queue and b.receive_latest() is None
+    for i in range(MessageInput.MAX_MESSAGES + 5):
+        a.push(i)
+    assert len(a.queue) == MessageInput.MAX_MESSAGES
+
+
+# ---- operators (tests/test_block.py) ----------------------------------------------------
+def test_pipe_operator():
+    with pytest.raises(AttributeError):
+        Block() | Block()
+    with pytest.raises(AttributeError):
+        Block(0, 1) | Block()
+    with pytest.raises(AttributeError):
+        Block() | Block(1, 0)
+    a, b = Block(0, 1), Block(1, 0)
+    assert (a | b) is b and connected(a, b)
+    a, b = Block(1, 1), Block(1, 1)
+    assert (a | b.input) is b and connected(a, b)
+    with pytest.raises(TypeError):
+        Block(1, 1) | Block(1, 1).output
+    with pytest.raises(TypeError):
+        Block(1, 1).input | Block(1, 1)
+    a, b = Block(1, 1), Block(1, 1)
+    assert (a.output | b) is b and connected(a, b)
+
+
+def test_mix_operator():
+    with pytest.raises(AttributeError):
+        Block() + Block()
+    with pytest.raises(AttributeError):
+        Block(0, 1) + Block()
+    a, b, c = Block(0, 1), Block(0, 1), Block(0, 1)
+    mixer = a + b + c
+    assert isinstance(mixer, Mixer) and mixer.nInputs == 3 and mixer.gains == [1., 1., 1.]
+    assert all(connected(x, mixer.inputs[i]) for i, x in enumerate((a, b, c)))
+    with pytest.raises(AttributeError):
+        Block(0, 1) + Block(0, 1).input
+    with pytest.raises(TypeError):
+        Block(1, 1).input + Block(1, 1)
+    a, b, c = Block(0, 1), Block(0, 1), Block(0, 1)
+    mixer = a.output + b + c.output
+    assert all(connected(x, mixer.inputs[i]) for i, x in enumerate((a, b, c)))
+    sm = StereoMixer()
+    sm += a
+    assert sm.pannings == [0.] and sm.nInputs == 1
+
+
+# ---- scheduler: the reference's golden orders (tests/test_graph.py:140-243) -----------------
+GOLDEN_ORDERS = [
+    ([(0, 1), (1, 2)], [0, 1, 2]),
+    ([(0, 1), (1, 2), (1, 3), (3, 1)], [0, 1, 3, 2]),
+    ([(0, 1), (1, 2), (2, 3), (0, 4), (4, 3)], [0, 4, 1, 2, 3]),
+    ([(0, 1), (1, 2), (2, 3), (0, 4), (4, 3), (2, 4)], [0, 1, 2, 4, 3]),
+    ([(0, 1), (1, 2), (2, 3), (0, 4), (4, 3), (4, 2)], [0, 4, 1, 2, 3]),
+    ([(0, 1), (1, 0)], [0, 1]),
+    ([(0, 1), (1, 0), (2, 3), (3, 2)], [0, 1, 2, 3]),
+    ([(0, 1), (1, 2), (2, 0)], [0, 1, 2]),
+    ([(0, 1), (0, 2), (1, 2), (1, 3), (2, 1), (2, 3)], [0, 1, 2, 3]),
+    ([(0, 1), (1, 2), (2, 6), (3, 4), (4, 5), (5, 6), (2, 4), (5, 1)], [0, 1, 2, 3, 4, 5, 6]),
+    ([(0, 1), (1, 2), (2, 3), (1, 2)], [0, 1, 2, 3]),
+    ([(1, 0), (2, 1), (3, 2), (4, 3), (5, 4), (4, 5)], [4, 5, 3, 2, 1, 0]),
+    ([(0, 1), (0, 2), (0, 3), (1, 2), (3, 4), (4, 5), (5, 3)], [0, 3, 4, 5, 1, 2]),
+]
+
+
+@pytest.mark.parametrize('edges,want', GOLDEN_ORDERS)
+def test_topological_order_goldens(edges, want):
+    n = max(max(e) for e in edges) + 1
+    assert topological_order(n, edges) == want
+
+
+def test_back_edges():
+    assert find_back_edges(3, [(0, 1), (1, 2), (2, 0)]) == [(2, 0)]
+    assert find_back_edges(3, [(0, 1), (1, 2)]) == []
+
+
+def test_execution_order_of_block_networks():
+    assert determine_execution_order([]) == []
+    blk = Block()
+    assert determine_execution_order([blk]) == [blk]
+    a, b, c = Block(1, 1), Block(1, 1), Block(1, 1)
+    assert determine_execution_order([a, b, c]) == [a, b, c]
+    b.output.connect(c.input)
+    assert determine_execution_order([a, b]) == [a, b, c]
+    x, y, z = Block(0, 1), Block(1, 1), Block(1, 0)
+    x | y | z
+    assert determine_execution_order([z]) == [x, y, z]
+
+
+def test_composite_and_unpatch():
+    src, block, d0, d1 = Block(0, 1), Block(1, 1), Block(1, 0), Block(1, 0)
+    src | block | d0
+    block | d1
+    with temporarily_unpatch(block):
+        assert not block.input.connected and not block.output.connected
+    assert block.input.incomingConnection is src.output
+    assert block.output.outgoingConnections == {d0.input, d1.input}
+    comp = Composite()
+    comp.inputs = [Relay(owner=comp), Relay(owner=comp)]
+    comp.outputs = [Relay(owner=comp), Relay(owner=comp)]
+    a, b = Block(1, 1), Block(1, 1)
+    comp.inputs[0] | a | comp.outputs[0]
+    comp.inputs[1] | b | comp.outputs[1]
+    comp.update_internal_exec_order()
+    assert comp.execOrder == [a, b]
+
+
+# ---- voice / note (tests/test_audio_voices.py) -----------------------------------------------
+def test_note_validation():
+    assert Note(69).frequency == 440. and Note(69).on and Note(69, 0.).off
+    for bad in (dict(pitch=-1), dict(pitch=128), dict(pitch=60, velocity=1.5),
+                dict(pitch=60, frequency=-1.)):
+        with pytest.raises(ValueError):
+            Note(**bad)
+    assert Note.from_json(Note(60, .5).to_json()) == Note(60, .5)
+
+
+def test_voice_lifecycle_on_host():
+    voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.001, .001, .5, .001))
+    assert [type(b).__name__ for b in voice.execOrder] == ['Oscillator', 'ADSR']
+    voice.update()
+    assert not voice.active and np.all(voice.output.value == 0.)   # silence before a note
+    voice.input.push(Note(60, .7))
+    assert voice.active                                            # pending message
+    voice.update()
+    assert voice.active and voice.amplitude == .7 and voice.currentPitch == 60
+    assert voice.oscillator.frequency.value == Note(60).frequency
+    voice.input.push(Note(60, 0.))
+    for _ in range(4):
+        voice.update()
+    assert not voice.active and voice.amplitude == .7 and voice.currentPitch == 0
+
+
+def test_envelope_attribute_validation_on_host():
+    env = AR(.1, 1.)
+    assert (env.decay, env.sustain) == (0., 1.)
+    for name in ('attack', 'decay', 'release', 'overshoot'):
+        with pytest.raises(ValueError):
+            setattr(env, name, -1.)
+    with pytest.raises(ValueError):
+        env.sustain = 1.5
+    env.overshoot = 0.
+    assert env.overshoot == 1e-9
+    with pytest.raises(ValueError):
+        env.sample(-1)
+    assert env.sample(0).size == 0
+
+
+def test_dac_channel_collection():
+    dac = Dac(nChannels=2)
+    dac.inputs[0].set_value(np.ones((2, 256)))
+    out = dac.collect_samples()
+    assert out.shape == (256, 2) and out.dtype == np.float32

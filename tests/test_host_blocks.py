@@ -1,0 +1,245 @@
+"""backend='host' evaluation of the mirrored blocks against the reference
+fixtures (tests/golden, made by tools/gen_golden.py), the hello_world config
+through run_klang(filepath=...), and the graph compiler's pattern matching
+(no device needed for the matching itself)."""
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from klang_amd import fusion, patches as P
+from klang_amd.audio import (ADSR, AR, BackwardCombFilter, Dac, EchoFilter, Filter,
+                             ForwardCombFilter, Lfo, Mixer, Oscillator, Phasor, PwmOscillator,
+                             Reverb, StereoMixer, Voice, sample_phase, sawtooth, sine, square,
+                             triangle)
+from klang_amd.audio.envelopes import Envelope
+from klang_amd.block import Block
+from klang_amd.errors import KlangError
+from klang_amd.klang import run_klang
+from klang_amd.messages import Note
+from klang_amd.schedule import determine_execution_order
+
+B = 256
+DT = 1. / 44100
+WAVES = {'sine': sine, 'square': square, 'sawtooth': sawtooth, 'triangle': triangle}
+
+
+class Source(Block):
+    def __init__(self, value):
+        super().__init__(nOutputs=1)
+        self.output.set_value(value)
+
+
+def test_sample_phase_and_waves_vs_golden(golden):
+    g = golden('phase_waves')
+    for i, f in enumerate(g['frequencies']):
+        for j, s in enumerate(g['starts']):
+            ph, nxt = sample_phase(f, s)
+            np.testing.assert_array_equal(ph, g['phase'][i, j])
+            assert nxt == g['next'][i, j]
+            for name, fn in WAVES.items():
+                np.testing.assert_array_equal(fn(ph), g[name][i, j])
+    freq = golden('inputs')['frequency_arrays']
+    cur = float(g['array_start'])
+    for b in range(3):
+        ph, cur = sample_phase(freq[b], cur)
+        np.testing.assert_array_equal(ph, g['array_phase'][b])
+    ph = Phasor(frequency=3.7, startPhase=.25)
+    pw = PwmOscillator(frequency=441., dutyCycle=.3)
+    ls = Lfo(frequency=2., shape=1, outputRange=(100., 1000.))
+    lv = Lfo(frequency=5., wave_func=triangle, shape=B, outputRange=(-2., 3.))
+    for b in range(4):
+        for blk in (ph, pw, ls, lv):
+            blk.update()
+        assert ph.output.value == g['phasor_3p7_start_0p25'][b]
+        np.testing.assert_array_equal(pw.output.value, g['pwm_441_0p3'][b])
+        assert ls.output.value == g['lfo_scalar'][b]
+        np.testing.assert_array_equal(lv.output.value, g['lfo_vector'][b])
+
+
+def test_host_envelope_vs_golden(golden):
+    g = golden('envelope')
+    for case in ('adsr_regate', 'ar_zero_attack', 'd_only', 'retrigger_on', 'retrigger_off',
+                 'loop_gate_off', 'overshoot_clip_low', 'overshoot_large', 'double_events'):
+        a, d, s, r, over, retrig, loop = g[case + '_params']
+        env = Envelope(a, d, s, r, DT, over, bool(retrig), bool(loop))
+        script = {}
+        for blk, gate in g[case + '_script']:
+            script.setdefault(int(blk), []).append(bool(gate))
+        out = []
+        for b in range(int(g[case + '_n_blocks'])):
+            for gate in script.get(b, ()):
+                env.gate(gate)
+            out.append(env.sample(B))
+        np.testing.assert_array_equal(np.concatenate(out), g[case + '_samples'])
+        assert env.active == bool(g[case + '_active'][-1])
+
+
+def test_host_filter_vs_golden(golden):
+    g = golden('filter')
+    x = golden('inputs')['noise'][:8 * B]
+    for c in (440., 2000., 5., 30000.):
+        f = Filter(frequency=c)
+        ys = []
+        for b in range(8):
+            f.input.set_value(x[b * B:(b + 1) * B])
+            f.update()
+            ys.append(f.output.value)
+        assert np.abs(np.concatenate(ys) - g['noise_%g' % c]).max() <= 1e-11
+    f = Filter(frequency=1000.)
+    f.input.set_value(np.stack([x[:B], x[B:2 * B]]))
+    f.update()
+    assert np.abs(f.output.value - g['stereo_1000']).max() <= 1e-11
+
+
+def test_host_ring_filters_and_reverb_vs_golden(golden):
+    g = golden('ring_filters')
+    x = golden('inputs')['noise']
+    for name, cls in (('forward', ForwardCombFilter), ('backward', BackwardCombFilter),
+                      ('echo', EchoFilter)):
+        for K in (1, 7, 234, 1327):
+            total = 1664 if K == 1327 else 640
+            f = cls(K, .9 if K != 7 else .5)
+            y = np.concatenate([f.filter(x[p:p + 123]) for p in range(0, total, 123)])
+            np.testing.assert_array_equal(y[:total], g['%s_K%d_bs123' % (name, K)])
+    with pytest.raises(ValueError):
+        BackwardCombFilter(5).filter(np.zeros((2, 4)))
+    with pytest.raises(RuntimeError):
+        BackwardCombFilter(60 * 44100 + 1)
+    r = golden('reverb')
+    rv = Reverb(decay=3., dryWet=.7)
+    assert [f.length for f in rv.filters] == list(r['taps_default'])
+    out = []
+    for b in range(24):
+        rv.input.set_value(x[b * B:(b + 1) * B])
+        rv.update()
+        out.append(rv.output.value)
+    np.testing.assert_allclose(np.concatenate(out), r['decay3_noise'], rtol=0, atol=1e-15)
+
+
+def test_host_mixers_vs_golden(golden):
+    g = golden('mixer')
+    x = golden('inputs')['mixer_inputs']
+    for n in (1, 2, 3, 64):
+        m = Mixer()
+        for c in range(n):
+            m += Source(x[c])
+            m.gains[-1] = g['gains'][c]
+        m.update()
+        np.testing.assert_array_equal(m.output.value, g['mono_%d' % n])
+    sm = StereoMixer()
+    for c in range(20):
+        sm += Source(x[c])
+        sm.gains[-1] = g['gains'][c]
+        sm.pannings[-1] = g['stereo_20_pannings'][c]
+    sm.update()
+    np.testing.assert_allclose(sm.output.value, g['stereo_20'], rtol=0, atol=2e-16)
+    with pytest.raises(ValueError):
+        StereoMixer(1, mode='bogus').update()
+
+
+def _polyphonic_patch(n=48):
+    p = P.polyphonic_saw_patch(n_voices=n, n_blocks=40, off_base=6, off_span=12)
+    mixer, voices = Mixer(), []
+    for v in range(n):
+        voice = Voice(Oscillator(wave_func=sawtooth),
+                      ADSR(p.attack[v], p.decay[v], p.sustain[v], p.release[v]))
+        fil = Filter(frequency=p.cutoff[v])
+        voice | fil
+        mixer += fil
+        voices.append(voice)
+    return p, mixer, voices
+
+
+def test_host_chain_config3_mini_vs_golden(golden):
+    g = golden('chains')
+    p, mixer, voices = _polyphonic_patch()
+    order = determine_execution_order([mixer])
+    by_block = {}
+    for ev in p.events:
+        note = Note(0, float(ev['velocity']) if ev['kind'] == 1 else 0., float(ev['frequency']))
+        by_block.setdefault(int(ev['block']), []).append((int(ev['voice']), note))
+    out = []
+    for b in range(12):
+        for v, note in by_block.get(b, ()):
+            voices[v].input.push(note)
+        for blk in order:
+            blk.update()
+        out.append(mixer.output.value)
+    assert np.abs(np.array(out) - g['config3_mini_mix'][:12]).max() <= 1e-12
+
+
+def test_hello_world_config_on_host(tmp_path, golden):
+    """BASELINE configs[0]: examples/hello_world.py, offline to WAV, CPU only."""
+    path = str(tmp_path / 'hello.wav')
+    osc = Oscillator(frequency=440.)
+    frames = run_klang(osc | Dac(), backend='host', filepath=path, offline=True, duration=1.0)
+    audio = np.concatenate(frames)
+    assert audio.shape == (172 * B, 1) and audio.dtype == np.float32
+    t = np.arange(172 * B) / 44100.
+    assert np.abs(audio[:, 0] - np.sin(2. * np.pi * 440. * t)).max() <= 1e-6
+    np.testing.assert_array_equal(audio[:4 * B, 0].reshape(4, B),
+                                  golden('hello_world')['first_blocks_f32'])
+    with wave.open(path, 'rb') as wav:
+        assert (wav.getnframes(), wav.getnchannels(), wav.getframerate()) == (44032, 1, 44100)
+        pcm = np.frombuffer(wav.readframes(-1), dtype='<i2')
+    assert np.abs(pcm).max() == 32767                      # peak-normalised, wavfile.py:60
+    with pytest.raises(KlangError):
+        run_klang(Oscillator() | Dac(), backend='host', offline=True)     # duration INF
+    with pytest.raises(ValueError):
+        run_klang()
+
+
+def test_fadeout_and_stereo_dump(tmp_path):
+    path = str(tmp_path / 'st.wav')
+    mixer = StereoMixer()
+    for f, pan in ((220., -1.), (330., 1.)):
+        mixer += Oscillator(frequency=f)
+        mixer.pannings[-1] = pan
+    frames = run_klang(mixer | Dac(nChannels=2), backend='host', filepath=path, offline=True,
+                       duration=.1, fadeout=.05)
+    audio = np.concatenate(frames)
+    assert audio.shape[1] == 2 and np.abs(audio[-1]).max() < 5e-2 < np.abs(audio[:B]).max()
+    assert os.path.getsize(path) == 44 + audio.size * 2
+
+
+# ---- graph compiler: pattern matching (no device) -------------------------------------------------
+def test_find_fusable_matches_voice_filter_mixer():
+    p, mixer, voices = _polyphonic_patch(6)
+    dac = mixer | Dac()
+    order = determine_execution_order([dac])
+    groups, errors = fusion.find_fusable(order)
+    assert not errors and len(groups) == 1
+    sink, chains = groups[0]
+    assert sink is mixer and len(chains) == 6
+    assert chains[0].shape == (True, True, None)
+    assert [c.voice for c in chains] == voices and chains[0].wave_id() == 2
+
+
+def test_find_fusable_single_chain_and_reverb_shape():
+    osc = Oscillator(440.)
+    dac = osc | Dac()
+    groups, errors = fusion.find_fusable(determine_execution_order([dac]))
+    assert not errors and [(s, len(c)) for s, c in groups] == [(osc, 1)]
+    voice = Voice(Oscillator(), AR(.01, 1.))
+    rv = Reverb(decay=3., dryWet=.7)
+    dac = voice | rv | Dac()
+    groups, errors = fusion.find_fusable(determine_execution_order([dac]))
+    assert not errors and groups[0][0] is rv
+    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10))
+
+
+def test_find_fusable_reports_what_it_cannot_fuse():
+    lfo = Lfo(frequency=2., outputRange=(200., 2000.))
+    osc, fil = Oscillator(wave_func=sawtooth), Filter()
+    lfo | fil.frequency            # modulated cutoff: a "next" row, not fused yet
+    dac = osc | fil | Dac()
+    groups, errors = fusion.find_fusable(determine_execution_order([dac]))
+    assert any('modulated cutoff' in e for e in errors)
+    shared = Oscillator()
+    m = Mixer()
+    m += shared
+    shared.output.connect(Block(1, 0).input)      # second consumer
+    _, errors = fusion.find_fusable(determine_execution_order([m]))
+    assert any('more than one input' in e for e in errors)
