@@ -122,6 +122,8 @@ class GpuVoiceBank(Block):
             reverb=dict(zip(('decay', 'pre_delay', 'dry_wet', 'n_echos'), reverb)) if reverb else None,
             **kw)
         self.lookahead = 1      # blocks rendered per device call (set by run_klang)
+        self.remaining = None   # buffers still to be delivered, when the caller knows (offline
+                                # bounce): rendering ahead never runs past the end of the piece
         self._ready = []
         self._upload()
 
@@ -196,8 +198,13 @@ class GpuVoiceBank(Block):
         if not self._ready:
             self._collect_events()
             # float32 [n][channels][256] -> per buffer (256,) mono or (2, 256) stereo
-            mix = self.bank.render(max(1, int(self.lookahead)))
+            ahead = max(1, int(self.lookahead))
+            if self.remaining is not None:
+                ahead = max(1, min(ahead, int(self.remaining)))
+            mix = self.bank.render(ahead)
             self._ready = [blk if self.stereo else blk[0] for blk in mix][::-1]
+        if self.remaining is not None:
+            self.remaining -= 1
         self.sink.output.set_value(self._ready.pop().astype(np.float64))
 
     def sync_host_blocks(self):

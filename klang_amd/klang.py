@@ -12,6 +12,8 @@ import logging
 
 from klang_amd.audio.engine import Adc, Dac, look_for_audio_blocks, run_audio_engine  # noqa: F401
 from klang_amd.composite import Composite
+from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
+from klang_amd.constants import INF
 from klang_amd.errors import KlangError
 from klang_amd.schedule import determine_execution_order
 
@@ -58,8 +60,11 @@ def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
         # rendering ahead is safe when nothing on the host can emit a note between buffers
         only_io = all(isinstance(b, (fusion.GpuVoiceBank, Adc, Dac)) for b in execOrder)
         ahead = (64 if only_io else 1) if lookahead is None else int(lookahead)
+        duration = kwargs.get('duration', INF)
+        n_cycles = None if duration == INF else int(duration * SAMPLING_RATE // BUFFER_SIZE)
         for bank in banks:
             bank.lookahead = ahead
+            bank.remaining = n_cycles
 
     def execute_all_blocks():
         for block in execOrder:
