@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Secondary measurements (one JSON line each) for the BASELINE configs that are
+not bench.py's headline: config 2 (haunting patch, replicated), config 3 in
+materialised mode (per-voice float32 streams written to HBM) and config 4
+(reverb channels, delay lines in HBM).  Usage:
+
+    python tools/bench_configs.py [2] [3m] [4] [4big]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from klang_amd import native, patches  # noqa: E402
+
+B = 256
+HBM_PEAK = 8000.
+
+
+def timed(fn, reps=3):
+    fn()
+    best = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        best.append(time.perf_counter() - t0)
+    return min(best), float(np.median(best))
+
+
+def bank_for(ctx, patch):
+    bank = native.Bank(ctx, patch.n_voices, has_env=patch.has_env, has_filter=patch.has_filter,
+                       stereo=patch.stereo, has_reverb='reverb' in patch,
+                       reverb=patch.get('reverb'))
+    ev = patch.events
+    p = patches.Patch(patch)
+    p['events'] = ev[:0]
+    bank.load_patch(p)
+    return bank, ev
+
+
+def queue(bank, ev, n_blocks, runs):
+    allev = []
+    for r in range(runs):
+        e = ev.copy()
+        e['block'] += r * n_blocks
+        allev.append(e)
+    bank.events(np.concatenate(allev))
+
+
+def config2(ctx):
+    n_blocks, replicas = 2048, 1024
+    patch = patches.haunting_patch(replicas=replicas, n_blocks=n_blocks)
+    bank, ev = bank_for(ctx, patch)
+    bank.events(ev)
+    best, med = timed(lambda: bank.render(n_blocks))
+    ms, launches = bank.last_kernel_ms()
+    units = patch.n_voices * n_blocks * B
+    return dict(config='2: haunting_envelopes x%d (%d looping AR sine voices -> StereoMixer), '
+                       '%d blocks' % (replicas, patch.n_voices, n_blocks),
+                value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
+                launches=launches)
+
+
+def config3_materialised(ctx):
+    import torch
+    n, n_blocks = 65536, 64
+    patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=n_blocks, off_base=10, off_span=20)
+    bank, ev = bank_for(ctx, patch)
+    bank.events(ev)
+    out = torch.empty((n, n_blocks * B), dtype=torch.float32, device='cuda')
+
+    def run():
+        bank.render_voices_device(n_blocks, out.data_ptr())
+        ctx.synchronize()
+    best, med = timed(run)
+    ms, launches = bank.last_kernel_ms()
+    units = n * n_blocks * B
+    algo = units * 4.594  # A3m = 4.594 B per voice-sample
+    return dict(config='3 materialised: 65,536 voices x %d blocks, one float32 stream per voice '
+                       'written to HBM' % n_blocks,
+                value=units / (ms * 1e-3), unit='voice-samples/s', wall_ms=med * 1e3,
+                kernel_ms=ms,
+                roofline=dict(bound='hbm', achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK,
+                              unit='GB/s', frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK,
+                              algorithmic_bytes_per_voice_sample=4.594))
+
+
+def config4(ctx, n_channels=4096, n_blocks=512):
+    patch = patches.reverb_patch(n_channels=n_channels, n_blocks=n_blocks)
+    bank, ev = bank_for(ctx, patch)
+    queue(bank, ev, n_blocks, 5)
+    best, med = timed(lambda: bank.render(n_blocks))
+    ms, launches = bank.last_kernel_ms()
+    units = n_channels * n_blocks * B
+    algo = units * 168.   # 10 combs x (8 B read + 8 B write) float64 rings + 8 B dry input
+    return dict(config='4: %d channels Voice(sine, AR(.01,1.)) -> Reverb(decay 3, dryWet .7) -> '
+                       'Mixer, %d blocks, float64 rings (%.2f GB of delay lines)'
+                       % (n_channels, n_blocks, n_channels * 13896 * 8 / 1e9),
+                value=units / med, unit='channel-samples/s', wall_ms=med * 1e3,
+                reverb_kernel_ms=ms, reverb_launches=launches,
+                roofline=dict(bound='hbm', achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK,
+                              unit='GB/s', frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK,
+                              kernel='reverb_kernel', algorithmic_bytes_per_channel_sample=168.,
+                              whole_call_frac=algo / med / 1e9 / HBM_PEAK))
+
+
+def main():
+    which = sys.argv[1:] or ['2', '3m', '4']
+    # torch bundles its own HIP runtime: it has to initialise before libklang_mi.so
+    # pulls in the system one ("PyTorch in the same process")
+    import torch
+    torch.cuda.init()
+    ctx = native.Context(0, torch.cuda.current_stream().cuda_stream)
+    for w in which:
+        if w == '2':
+            r = config2(ctx)
+        elif w == '3m':
+            r = config3_materialised(ctx)
+        elif w == '4':
+            r = config4(ctx)
+        elif w == '4big':
+            r = config4(ctx, 16384, 128)
+        else:
+            raise SystemExit('unknown config %r' % w)
+        print(json.dumps(r), flush=True)
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()
