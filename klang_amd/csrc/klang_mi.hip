@@ -399,6 +399,8 @@ struct klmi_bank {
     DevBuf<int32_t> d_taps, d_ring_offset;
     std::vector<int32_t> ring_pos;  // host-tracked, identical for every voice
     DevBuf<float> rv_partial;
+    hipStream_t aux_stream = nullptr;            // dry-voice kernels of reverb banks
+    hipEvent_t rv_start = nullptr, rv_ready[2] = {nullptr, nullptr}, rv_done[2] = {nullptr, nullptr};
 
     // timing
     std::vector<hipEvent_t> ev_start, ev_stop;
@@ -589,6 +591,16 @@ static void destroy_events(klmi_bank *b)
         (void)hipEventDestroy(e);
     b->ev_start.clear();
     b->ev_stop.clear();
+    if (b->aux_stream) {
+        (void)hipStreamSynchronize(b->aux_stream);
+        (void)hipStreamDestroy(b->aux_stream);
+        (void)hipEventDestroy(b->rv_start);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(b->rv_ready[i]);
+            (void)hipEventDestroy(b->rv_done[i]);
+        }
+        b->aux_stream = nullptr;
+    }
 }
 
 extern "C" int klmi_bank_destroy(klmi_bank *bank)
@@ -1168,9 +1180,28 @@ static int bank_init_reverb(klmi_bank *b)
     return 0;
 }
 
+static int reverb_streams(klmi_bank *b)
+{
+    if (b->aux_stream)
+        return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&b->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->rv_start, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&b->rv_ready[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->rv_done[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// Dry voices and reverb are pipelined over chunks of a few blocks: the voice
+// kernel of chunk j+1 (few waves, float64-VALU bound) runs on a side stream while
+// the reverb kernels of chunk j (HBM bound) run on the context's stream; two dry
+// buses alternate.  Order is carried by events only: ready[i] (dry bus i written),
+// done[i] (reverb finished reading dry bus i).
 static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
 {
-    hipStream_t st = b->ctx->stream;
+    TRY(reverb_streams(b));
+    hipStream_t st = b->ctx->stream, aux = b->aux_stream;
     ReverbState &r = b->reverb;
     const size_t n = (size_t)b->n;
     // time slab: as many samples as are independent of each other (< shortest ring),
@@ -1179,20 +1210,33 @@ static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
     if (slab >= kBlock)
         slab = (slab / kBlock) * kBlock;
     const int slab_blocks = std::max(1, slab / kBlock);
-    const int chunk_blocks = std::min(n_blocks, std::max(slab_blocks, 64));
-    HIP_TRY(b->bus_f64.reserve((size_t)chunk_blocks * kBlock * n));
+    const int chunk_blocks = std::min(n_blocks, std::max(slab_blocks, 8));
+    const size_t bus_elems = (size_t)chunk_blocks * kBlock * n;
+    HIP_TRY(b->bus_f64.reserve(2 * bus_elems));
     const int wave_groups = (b->n + 63) / 64;
-    HIP_TRY(b->rv_partial.reserve((size_t)wave_groups * chunk_blocks * kBlock));
+    const size_t partial_stride = (size_t)chunk_blocks * kBlock;
+    HIP_TRY(b->rv_partial.reserve(2 * (size_t)wave_groups * partial_stride));
     BankView view = make_view(b);
     b->timed_launches = 0;
-    for (int base = 0; base < n_blocks; base += chunk_blocks) {
+    // the side stream starts after everything already queued on the main stream
+    HIP_TRY(hipEventRecord(b->rv_start, st));
+    HIP_TRY(hipStreamWaitEvent(aux, b->rv_start, 0));
+    int chunk = 0;
+    for (int base = 0; base < n_blocks; base += chunk_blocks, ++chunk) {
         const int nb = std::min(chunk_blocks, n_blocks - base);
-        // 1) dry voices for nb blocks -> bus_f64[sample][voice]
-        hipError_t e = dispatch_voice<OUT_BUS_F64>(b->desc.has_env, b->desc.has_filter, st, view, 0,
-                                                   b->n, base, b->block_clock + (uint32_t)base, nb,
-                                                   0, nullptr, b->bus_f64.p);
+        const int buf = chunk & 1;
+        double *bus = b->bus_f64.p + (size_t)buf * bus_elems;
+        float *partial = b->rv_partial.p + (size_t)buf * wave_groups * partial_stride;
+        // 1) dry voices for nb blocks -> bus[sample][voice], on the side stream
+        if (chunk >= 2)
+            HIP_TRY(hipStreamWaitEvent(aux, b->rv_done[buf], 0));
+        hipError_t e = dispatch_voice<OUT_BUS_F64>(b->desc.has_env, b->desc.has_filter, aux, view,
+                                                   0, b->n, base, b->block_clock + (uint32_t)base,
+                                                   nb, 0, nullptr, bus);
         if (e != hipSuccess)
             return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(b->rv_ready[buf], aux));
+        HIP_TRY(hipStreamWaitEvent(st, b->rv_ready[buf], 0));
         // 2) combs + dry/wet + cross-voice sum, one launch per independent time slab
         const int total = nb * kBlock;
         for (int s0 = 0; s0 < total; s0 += slab) {
@@ -1202,20 +1246,19 @@ static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
             TRY(timing_begin(b, b->timed_launches));
             const dim3 grid((unsigned)wave_groups, (unsigned)((ns + kReverbSamplesPerWave - 1) /
                                                               kReverbSamplesPerWave));
-            hipLaunchKernelGGL(reverb_kernel, grid, dim3(64), 0, st, r,
-                               b->bus_f64.p + (size_t)s0 * n, ns, b->gain_l.p,
-                               b->rv_partial.p + (size_t)s0, (size_t)chunk_blocks * kBlock);
+            hipLaunchKernelGGL(reverb_kernel, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n, ns,
+                               b->gain_l.p, partial + (size_t)s0, partial_stride);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
             b->timed_launches++;
             for (int k = 0; k < r.n_echos; ++k)
                 b->ring_pos[k] = (b->ring_pos[k] + ns) % r.length[k];
         }
+        HIP_TRY(hipEventRecord(b->rv_done[buf], st));
         const size_t bus_len = (size_t)total;
         hipLaunchKernelGGL(bus_reduce_strided_kernel, dim3((unsigned)((bus_len + 255) / 256)),
-                           dim3(256), 0, st, b->rv_partial.p, wave_groups,
-                           (size_t)chunk_blocks * kBlock, bus_len, b->mix_divisor,
-                           dev_mix + (size_t)base * kBlock);
+                           dim3(256), 0, st, partial, wave_groups, partial_stride, bus_len,
+                           b->mix_divisor, dev_mix + (size_t)base * kBlock);
         HIP_TRY(hipGetLastError());
     }
     b->block_clock += (uint32_t)n_blocks;
