@@ -255,13 +255,15 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                     if (ENV) {
                         double e[8];
                         double vv = es.value;
-                        bool hit = false;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             vv = es.base + vv * es.coef;
-                            hit |= es.rising ? (vv >= es.limit) : (vv <= es.limit);
                             e[j] = vv;
                         }
+                        // v -> fl(base + fl(v*coef)) is monotone in v, so the 8 values
+                        // move in one direction: if any of them crossed the stage's
+                        // limit, the last one did (or they all lie beyond it).
+                        const bool hit = es.rising ? (vv >= es.limit) : (vv <= es.limit);
                         if (__any(hit)) {  // rare: exact state machine for the whole wave
 #pragma unroll
                             for (int j = 0; j < 8; ++j)

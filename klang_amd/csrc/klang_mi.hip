@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -1244,10 +1245,21 @@ static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
             for (int k = 0; k < r.n_echos; ++k)
                 r.position[k] = b->ring_pos[k];
             TRY(timing_begin(b, b->timed_launches));
-            const dim3 grid((unsigned)wave_groups, (unsigned)((ns + kReverbSamplesPerWave - 1) /
-                                                              kReverbSamplesPerWave));
-            hipLaunchKernelGGL(reverb_kernel, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n, ns,
-                               b->gain_l.p, partial + (size_t)s0, partial_stride);
+            static const int spw = [] {
+                const char *e = getenv("KLMI_REVERB_SPW");   // tuning knob, default 4
+                const int v = e ? atoi(e) : kReverbSamplesPerWave;
+                return (v == 2 || v == 8) ? v : 4;
+            }();
+            const dim3 grid((unsigned)wave_groups, (unsigned)((ns + spw - 1) / spw));
+            if (spw == 2)
+                hipLaunchKernelGGL(reverb_kernel<2>, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n,
+                                   ns, b->gain_l.p, partial + (size_t)s0, partial_stride);
+            else if (spw == 8)
+                hipLaunchKernelGGL(reverb_kernel<8>, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n,
+                                   ns, b->gain_l.p, partial + (size_t)s0, partial_stride);
+            else
+                hipLaunchKernelGGL(reverb_kernel<4>, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n,
+                                   ns, b->gain_l.p, partial + (size_t)s0, partial_stride);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
             b->timed_launches++;

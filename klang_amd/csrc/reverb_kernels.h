@@ -16,7 +16,7 @@
 namespace klmi {
 
 constexpr int kMaxEchos = 16;
-constexpr int kReverbSamplesPerWave = 4;
+constexpr int kReverbSamplesPerWave = 4;   // default; 2 and 8 are instantiated for tuning
 
 struct ReverbState {
     int n;         // voices
@@ -41,6 +41,7 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 // grid = (ceil(n/64), ceil(ns / kReverbSamplesPerWave)), block = 64.
 // x: [ns][n] dry input; partial[group * partial_stride + s] = sum over the
 // wave's voices of gain * Reverb(x) at slab sample s.
+template <int SPW>
 __global__ __launch_bounds__(64) void reverb_kernel(ReverbState r, const double *__restrict__ x,
                                                     int ns, const double *__restrict__ gain,
                                                     float *__restrict__ partial,
@@ -48,13 +49,13 @@ __global__ __launch_bounds__(64) void reverb_kernel(ReverbState r, const double 
 {
     const int v = blockIdx.x * 64 + threadIdx.x;
     const bool live = v < r.n;
-    const int s_begin = blockIdx.y * kReverbSamplesPerWave;
+    const int s_begin = blockIdx.y * SPW;
     const size_t n = (size_t)r.n;
     const double g = live ? gain[v] : 0.;
     const double echo_count = (double)r.n_echos;
 
-    double xin[kReverbSamplesPerWave];
-    double old[kReverbSamplesPerWave][kMaxEchos];
+    double xin[SPW];
+    double old[SPW][kMaxEchos];
 
     // Row of comb k at slab sample s (wave-uniform: scalar registers).  s < ns <=
     // min_length <= length and position < length, so one conditional subtract wraps.
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(64) void reverb_kernel(ReverbState r, const double 
 
     // issue every load of this wave first (they are independent of its stores)
 #pragma unroll
-    for (int j = 0; j < kReverbSamplesPerWave; ++j) {
+    for (int j = 0; j < SPW; ++j) {
         const int s = s_begin + j;
         const bool on = live && s < ns;
         xin[j] = on ? x[(size_t)s * n + v] : 0.;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) void reverb_kernel(ReverbState r, const double 
     }
 
 #pragma unroll
-    for (int j = 0; j < kReverbSamplesPerWave; ++j) {
+    for (int j = 0; j < SPW; ++j) {
         const int s = s_begin + j;
         if (s >= ns)
             break;
