@@ -151,7 +151,7 @@ def main():
 
     if rank == 0:
         peak = float(host_bus.abs().max())
-        assert np.isfinite(peak) and peak > 1e-4, 'mix bus is silent or not finite'
+        assert np.isfinite(peak) and peak > 1e-4, 'mix bus is silent or not finite (peak %r)' % peak
         units = n_total * BLOCKS_PER_STEP * B * args.steps
         value = units / elapsed
         per_launch_units = VOICES_PER_GPU * BLOCKS_PER_STEP * B / max(launches, 1)

@@ -146,8 +146,10 @@ const char *klmi_last_error(void);
 const char *klmi_version(void);
 
 /* ---- context ------------------------------------------------------------ */
-/* One GPU.  `stream` is a hipStream_t the launches are ordered on (e.g.
- * torch.cuda.current_stream().cuda_stream) or NULL for a library-owned one. */
+/* One GPU.  `stream` is the hipStream_t every launch and copy is ordered on
+ * (e.g. torch.cuda.current_stream().cuda_stream); NULL is the device's default
+ * (null) stream, as in every HIP call -- which is also what torch reports (0)
+ * while no side stream is current. */
 int klmi_ctx_create(int device, void *stream, klmi_ctx **out);
 int klmi_ctx_destroy(klmi_ctx *ctx);
 int klmi_ctx_synchronize(klmi_ctx *ctx);
@@ -158,6 +160,9 @@ int klmi_ctx_synchronize(klmi_ctx *ctx);
 int klmi_filter_grid(double *freqs /* [KLMI_GRID_POINTS] */);
 int klmi_filter_grid_index(double frequency);  /* effects.py:271-274; returns the row */
 int klmi_butter2_lowpass(double wn, double b[3], double a[3]);
+/* effects.py:33-55 low_pass_coefficients: single-pole low-pass, a1 = -exp(-TAU f / SR),
+ * b0 = 1 - |a1|; f == 0 -> ([0], [1, -1]); f == inf -> ([1], [1, 0]). */
+int klmi_low_pass_coefficients(double frequency, double b[1], double a[2]);
 /* _envelope.c:112-119, 187-198: {attackCoef, attackBase, decayCoef, decayBase,
  * releaseCoef, releaseBase}. */
 int klmi_envelope_coefficients(double attack, double decay, double sustain, double release,

@@ -12,6 +12,9 @@
 #include "dsp_device.h"
 #include <type_traits>
 
+#ifndef KLMI_GROUP
+#define KLMI_GROUP 8
+#endif
 namespace klmi {
 
 // t[n] = DT * n, n = 0..256 (helpers.py:27-32), padded to whole groups of 8
@@ -61,6 +64,9 @@ template <> struct TileTraits<OUT_VOICES_F32> { using T = float; static constexp
 template <> struct TileTraits<OUT_VOICES_F64> { using T = double; static constexpr int chunk = 32, stride = 65, planes = 1; };
 template <> struct TileTraits<OUT_BUS_F64> { using T = double; static constexpr int chunk = 64, stride = 1, planes = 0; };
 
+// high 32 bits of TAU = 0x401921FB54442D18
+constexpr uint32_t kTauHighWord = 0x401921FBu;
+
 constexpr int kWavesPerGroup = 4;
 constexpr int kGroup = 64 * kWavesPerGroup;
 
@@ -83,7 +89,7 @@ __device__ __forceinline__ float row_sum64(const float *row)
 }
 
 // grid.x = ceil(count / 256) workgroups of 4 waves.
-// partial: [gridDim.x][n_blocks*planes*256] float32 (mix modes)
+// partial: [gridDim.x * 4 waves][n_blocks*planes*256] float32 (mix modes)
 // out:     voices / bus buffer (other modes)
 template <bool ENV, bool FILT, int MODE>
 __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, int count,
@@ -106,9 +112,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     const int wave = threadIdx.x >> 6;
     // wave-private tile(s): [PLANES][CH][stride]
     T *tile = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (PLANES ? PLANES : 1) * CH * TT::stride;
-    // cross-wave combine area (mix modes): [waves][PLANES][CH] floats after the tiles
-    float *xwave = reinterpret_cast<float *>(
-        smem_raw + sizeof(T) * (size_t)kWavesPerGroup * (PLANES ? PLANES : 1) * CH * TT::stride);
+
 
     const int local = blockIdx.x * kGroup + threadIdx.x;
     const bool live = local < count;
@@ -155,10 +159,13 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     }
 
     double gl = 0., gr = 0.;
+    bool unit_gain = false;  // wave-uniform: every live lane's gain is exactly 1 (plain Mixer)
     if (MIX) {
         gl = live ? bk.gain_l[v] : 0.;
         if (MODE == OUT_MIX_STEREO)
             gr = live ? bk.gain_r[v] : 0.;
+        else
+            unit_gain = __all(gl == 1.);
     }
 
     // ---- event cursor -------------------------------------------------------------
@@ -204,112 +211,156 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             // wavefront agrees on it (compile-time dispatch), or -1 (per-lane switch).
             // FAST: every lane's phase argument of this block is >= 0 and < 1e9, so
             // the remainder needs no sign handling and no library fallback.
-            auto run_chunk = [&](auto wk, auto fast) {
+            auto run_chunk = [&](auto wk, auto fast, auto unit) {
                 constexpr int WK = decltype(wk)::value;
                 constexpr bool FAST = decltype(fast)::value;
-                for (int i8 = 0; i8 < CH; i8 += 8) {
-                    // 8 time points per scalar load (wave-uniform index)
-                    const Time8 tt = reinterpret_cast<const Time8 *>(c_time)[(c * CH + i8) >> 3];
+                constexpr bool UNIT = decltype(unit)::value;  // gains are 1: 1. * x == x
+                // 8 time points per scalar load (wave-uniform index).  Fetching them a group
+                // ahead was measured slower (more scalar registers live across the group).
+                const Time8 *times = reinterpret_cast<const Time8 *>(c_time) + ((c * CH) >> 3);
+                auto group8 = [&](int i8, const Time8 *tp) {
+                    constexpr int G = KLMI_GROUP;
+                    Time8 tt[G / 8];
+#pragma unroll
+                    for (int q = 0; q < G / 8; ++q)
+                        tt[q] = tp[q];
                     const int wsel = (WK >= 0) ? WK : wave_id;
-                    double xs[8];
+                    // Eight samples as ONE straight-line region: oscillator (8 independent
+                    // samples), envelope and biquad recurrences (serial chains) are all
+                    // computed speculatively so that the scheduler can interleave the chains
+                    // with the independent work.  Speculation: "no lane needs the remainder
+                    // repair and no lane's envelope switches stage in these 8 samples".  The
+                    // lane masks of the checks are OR-ed on the scalar unit; on a hit the whole
+                    // wave redoes the 8 samples with the exact per-sample code from the state
+                    // at the start of the group (nothing was committed).
+                    unsigned long long redo = 0;
+                    double arg[G], osc[G], y[G];
+                    const bool has_phase = (wsel != W_EXTERNAL && wsel != W_ONE);
 
-                    // -- oscillator: 8 independent samples, straight-line -------------
+                    // -- oscillator --------------------------------------------------------
                     if (wsel == W_EXTERNAL) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            xs[j] = bk.ext_input[(size_t)(block_base * kBlock + s0 + i8 + j) * bk.n + v];
+                        for (int j = 0; j < G; ++j)
+                            osc[j] = bk.ext_input[(size_t)(block_base * kBlock + s0 + i8 + j) * bk.n + v];
                     } else if (wsel == W_ONE) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            xs[j] = 1.;
+                        for (int j = 0; j < G; ++j)
+                            osc[j] = 1.;
                     } else {
-                        double ph[8];
-                        if constexpr (FAST) {
-                            // remainder without repair; one wave-level branch per 8
-                            // samples redoes them exactly if any lane needs the repair
-                            double arg[8];
-                            bool bad = false;
+                        // 0 <= ph < TAU, conservatively, on the high words only: non-negative
+                        // doubles order like their bit patterns and a set sign bit compares
+                        // high, so one unsigned maximum over the 8 high words and ONE compare
+                        // replace 8 compares (a false alarm just takes the exact path)
+                        uint32_t hi_max = 0;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                arg[j] = omega * tt.t[j] + start;
+                        for (int j = 0; j < G; ++j) {
+                            arg[j] = omega * tt[j >> 3].t[j & 7] + start;  // oscillators.py:60
+                            if constexpr (FAST) {
                                 const double k = floor(arg[j] * kInvTau);
-                                ph[j] = __builtin_fma(-k, kTau, arg[j]);
-                                bad |= !in_zero_tau(ph[j]);
+                                const double ph = __builtin_fma(-k, kTau, arg[j]);
+                                hi_max = max(hi_max, (uint32_t)__double2hiint(ph));
+                                osc[j] = wave_eval<true>(wsel, ph, duty_edge);
+                            } else {
+                                osc[j] = wave_eval<false>(wsel, np_mod_tau(arg[j]), duty_edge);
                             }
-                            if (__any(bad)) {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j)
-                                    ph[j] = fmod_tau_fast(arg[j]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                ph[j] = np_mod_tau(omega * tt.t[j] + start);
                         }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            xs[j] = wave_eval<FAST>(wsel, ph[j], duty_edge);
+                        if constexpr (FAST)
+                            redo |= __builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord);
                     }
 
-                    // -- envelope: speculate "no stage switch in these 8 samples" ------
+                    // -- envelope: v -> fl(base + fl(v*coef)) is monotone in v, so the 8
+                    // values move one way: if any crossed the stage's limit, the last did
+                    double vv = 0.;
                     if (ENV) {
-                        double e[8];
-                        double vv = es.value;
+                        vv = es.value;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            vv = es.base + vv * es.coef;
-                            e[j] = vv;
+                        for (int j = 0; j < G; ++j) {
+                            vv = es.base + vv * es.coef;           // _envelope.c:579-624
+                            y[j] = amp * osc[j] * vv;              // voices.py:73 (amplitude*osc)*env
                         }
-                        // v -> fl(base + fl(v*coef)) is monotone in v, so the 8 values
-                        // move in one direction: if any of them crossed the stage's
-                        // limit, the last one did (or they all lie beyond it).
-                        const bool hit = es.rising ? (vv >= es.limit) : (vv <= es.limit);
-                        if (__any(hit)) {  // rare: exact state machine for the whole wave
+                        redo |= __builtin_amdgcn_ballot_w64(es.reached(vv));
+                    } else {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                e[j] = es.step(ep);
-                        } else {
-                            es.value = vv;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            xs[j] = amp * xs[j] * e[j];  // voices.py:73 (amplitude * osc) * env
+                        for (int j = 0; j < G; ++j)
+                            y[j] = osc[j];
                     }
 
-                    // -- biquad (serial) and output -----------------------------------------
+                    // -- biquad (serial chain) on a copy of the state ------------------------
+                    Biquad sp = bq;
+                    if (FILT) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int i = i8 + j;
-                        double x = xs[j];
+                        for (int j = 0; j < G; ++j)
+                            y[j] = sp.step(y[j]);
+                    }
+
+                    if (__builtin_expect(redo != 0, 0)) {
+                        // exact path, from the uncommitted state
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            double x = osc[j];
+                            if constexpr (FAST) {
+                                if (has_phase)
+                                    x = wave_eval<true>(wsel, fmod_tau_fast(arg[j]), duty_edge);
+                            }
+                            if (ENV)
+                                x = amp * x * es.step(ep);
+                            if (FILT)
+                                x = bq.step(x);
+                            y[j] = x;
+                        }
+                    } else {
+                        if (ENV)
+                            es.value = vv;
                         if (FILT)
-                            x = bq.step(x);
-                        if constexpr (MODE == OUT_MIX_MONO) {
-                            tile[i * TT::stride + lane] = (float)(gl * x);
-                        } else if constexpr (MODE == OUT_MIX_STEREO) {
-                            tile[i * TT::stride + lane] = (float)(gl * x);
-                            tile[(CH + i) * TT::stride + lane] = (float)(gr * x);
-                        } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
-                            tile[i * TT::stride + lane] = (T)x;
-                        } else {
-                            if (live)
-                                reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
+                            bq.z0 = sp.z0, bq.z1 = sp.z1;
+                    }
+
+                    // -- output ----------------------------------------------------------------
+                    {
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const int i = i8 + j;
+                            const double x = y[j];
+                            if constexpr (MODE == OUT_MIX_MONO) {
+                                tile[i * TT::stride + lane] = UNIT ? (float)x : (float)(gl * x);
+                            } else if constexpr (MODE == OUT_MIX_STEREO) {
+                                tile[i * TT::stride + lane] = (float)(gl * x);
+                                tile[(CH + i) * TT::stride + lane] = (float)(gr * x);
+                            } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
+                                tile[i * TT::stride + lane] = (T)x;
+                            } else {
+                                if (live)
+                                    reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
+                            }
                         }
                     }
-                }
+                };
+                for (int i8 = 0; i8 < CH; i8 += KLMI_GROUP)
+                    group8(i8, times + (i8 >> 3));
             };
             using std::integral_constant;
             using Fast = std::true_type;
-            if (fast_block) {
-                switch (uniform_wave) {
-                case W_SINE: run_chunk(integral_constant<int, W_SINE>{}, Fast{}); break;
-                case W_SQUARE: run_chunk(integral_constant<int, W_SQUARE>{}, Fast{}); break;
-                case W_SAWTOOTH: run_chunk(integral_constant<int, W_SAWTOOTH>{}, Fast{}); break;
-                case W_TRIANGLE: run_chunk(integral_constant<int, W_TRIANGLE>{}, Fast{}); break;
-                case W_PWM: run_chunk(integral_constant<int, W_PWM>{}, Fast{}); break;
-                default: run_chunk(integral_constant<int, -1>{}, Fast{}); break;
+            auto dispatch = [&](auto unit) {
+                if (fast_block) {
+                    switch (uniform_wave) {
+                    case W_SINE: run_chunk(integral_constant<int, W_SINE>{}, Fast{}, unit); break;
+                    case W_SQUARE: run_chunk(integral_constant<int, W_SQUARE>{}, Fast{}, unit); break;
+                    case W_SAWTOOTH: run_chunk(integral_constant<int, W_SAWTOOTH>{}, Fast{}, unit); break;
+                    case W_TRIANGLE: run_chunk(integral_constant<int, W_TRIANGLE>{}, Fast{}, unit); break;
+                    case W_PWM: run_chunk(integral_constant<int, W_PWM>{}, Fast{}, unit); break;
+                    default: run_chunk(integral_constant<int, -1>{}, Fast{}, unit); break;
+                    }
+                } else {
+                    run_chunk(integral_constant<int, -1>{}, std::false_type{}, unit);
                 }
+            };
+            if constexpr (MODE == OUT_MIX_MONO) {
+                if (unit_gain)
+                    dispatch(std::true_type{});
+                else
+                    dispatch(std::false_type{});
             } else {
-                run_chunk(integral_constant<int, -1>{}, std::false_type{});
+                dispatch(std::false_type{});
             }
             // the tile is wave-private: LDS operations of one wave execute in order;
             // the fence only stops the compiler from moving them across this point
@@ -317,26 +368,16 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             __builtin_amdgcn_wave_barrier();
 
             if constexpr (MIX) {
-                // lane = sample: sum the 64 voices of this wave, then the 4 waves
+                // lane = sample: sum the 64 voices of this wave; one partial row per WAVE,
+                // so the waves of a workgroup never wait for each other
 #pragma unroll
                 for (int pl = 0; pl < PLANES; ++pl) {
                     for (int r = lane; r < CH; r += 64) {
-                        xwave[(wave * PLANES + pl) * CH + r] =
+                        const size_t o = ((size_t)b * PLANES + pl) * kBlock + c * CH + r;
+                        partial[(size_t)(blockIdx.x * kWavesPerGroup + wave) * n_blocks * PLANES * kBlock + o] =
                             row_sum64(tile + (size_t)(pl * CH + r) * TT::stride);
                     }
                 }
-                __syncthreads();
-                for (int idx = threadIdx.x; idx < PLANES * CH; idx += kGroup) {
-                    const int pl = idx / CH, r = idx % CH;
-                    float acc = xwave[(0 * PLANES + pl) * CH + r];
-#pragma unroll
-                    for (int w = 1; w < kWavesPerGroup; ++w)
-                        acc += xwave[(w * PLANES + pl) * CH + r];
-                    // partial layout per group: [block][plane][256]
-                    const size_t o = ((size_t)b * PLANES + pl) * kBlock + c * CH + r;
-                    partial[(size_t)blockIdx.x * n_blocks * PLANES * kBlock + o] = acc;
-                }
-                __syncthreads();
             } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
                 // lane = sample: write 64 voice rows, CH contiguous samples each
                 T *o = reinterpret_cast<T *>(out);
@@ -375,16 +416,48 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     }
 }
 
-// bus[s] = (sum over workgroups, fixed order, float64) / divisor -> float32.
-__global__ void bus_reduce_kernel(const float *__restrict__ partial, int n_groups, size_t bus_len,
+// Deterministic bus reduction in two steps (no float atomics anywhere):
+//   stage[slice][s] = sum of the partial rows of `slice` (ascending, float64)
+//   bus[s]          = (sum of the slices, ascending, float64) / divisor -> float32
+// The slice count depends on the row count only, so the association is fixed for
+// a given bank size.  One thread owns 4 consecutive samples (16-byte loads).
+constexpr int kBusSlices = 32;
+
+__host__ __device__ inline int bus_slices(int n_rows)
+{
+    return n_rows < kBusSlices ? n_rows : kBusSlices;
+}
+
+// grid = (ceil(bus_len / 1024), slices), block = 256; bus_len is a multiple of 256
+__global__ __launch_bounds__(256) void bus_slice_kernel(const float *__restrict__ partial,
+                                                        int n_rows, size_t bus_len,
+                                                        double *__restrict__ stage)
+{
+    const size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (s >= bus_len)
+        return;
+    const int slices = gridDim.y;
+    const int r0 = (int)((long long)n_rows * blockIdx.y / slices);
+    const int r1 = (int)((long long)n_rows * (blockIdx.y + 1) / slices);
+    double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+        const float4 p = *reinterpret_cast<const float4 *>(partial + (size_t)r * bus_len + s);
+        a0 += (double)p.x, a1 += (double)p.y, a2 += (double)p.z, a3 += (double)p.w;
+    }
+    double *o = stage + (size_t)blockIdx.y * bus_len + s;
+    o[0] = a0, o[1] = a1, o[2] = a2, o[3] = a3;
+}
+
+__global__ void bus_finish_kernel(const double *__restrict__ stage, int slices, size_t bus_len,
                                   double divisor, float *__restrict__ bus)
 {
     const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= bus_len)
         return;
     double acc = 0.;
-    for (int g = 0; g < n_groups; ++g)
-        acc += (double)partial[(size_t)g * bus_len + s];
+    for (int k = 0; k < slices; ++k)
+        acc += stage[(size_t)k * bus_len + s];
     bus[s] = (float)(acc / divisor);
 }
 

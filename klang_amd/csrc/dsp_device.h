@@ -156,6 +156,7 @@ struct EnvState {
     // recurrence of the current stage
     double coef, base, limit;
     bool rising;
+    uint32_t flip;  // 0 when rising, the sign bit (of a high word) when falling
 
     __device__ __forceinline__ void select(const EnvParams &p)
     {
@@ -176,6 +177,18 @@ struct EnvState {
             coef = 0., base = 0., limit = -__builtin_inf(), rising = false;
             break;
         }
+        flip = rising ? 0u : 0x80000000u;
+    }
+
+    // "value v reached the stage's limit" (v >= limit when rising, v <= limit when
+    // falling) as ONE compare: d = fl(v - limit) is >= 0 resp. <= 0 exactly when v is,
+    // and flipping d's sign for a falling stage turns "<= 0" into ">= 0" (-0 == +0).
+    // limit = -inf (sustain, off): d = +inf, flipped -inf: never a hit.
+    __device__ __forceinline__ bool reached(double v) const
+    {
+        const double d = v - limit;
+        const double f = __hiloint2double((int)((uint32_t)__double2hiint(d) ^ flip), __double2loint(d));
+        return f >= 0.;
     }
 
     // _envelope.c:549-567

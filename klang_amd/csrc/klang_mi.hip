@@ -195,8 +195,8 @@ template <typename T> struct DevBuf {
 struct klmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
     int live_objects = 0;            // banks / batches created on this context
+    int n_cus = 256;                 // compute units of the device
     std::vector<double> grid;        // 1000 frequencies
     std::vector<double> table;       // [1000][5] b0 b1 b2 a1 a2
     DevBuf<double> d_table;
@@ -222,15 +222,14 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
     HIP_TRY(hipSetDevice(device));
     klmi_ctx *ctx = new klmi_ctx;
     ctx->device = device;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
-        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            delete ctx;
-            return fail(KLMI_E_DEVICE, "hipStreamCreate failed: %s", hipGetErrorString(e));
-        }
-        ctx->own_stream = true;
+    // NULL is the device's default (null) stream, as everywhere in HIP: it is also what
+    // torch.cuda.current_stream().cuda_stream is (0) unless a side stream is current, so
+    // launches stay ordered with the caller's own work on that stream.
+    ctx->stream = (hipStream_t)stream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->n_cus = prop.multiProcessorCount;
     }
     ctx->grid.resize(KLMI_GRID_POINTS);
     make_grid(ctx->grid.data());
@@ -255,8 +254,6 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
     if (e == hipSuccess)
         e = hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof t);
     if (e != hipSuccess) {
-        if (ctx->own_stream)
-            (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return fail(KLMI_E_DEVICE, "context setup failed: %s", hipGetErrorString(e));
     }
@@ -273,8 +270,6 @@ extern "C" int klmi_ctx_destroy(klmi_ctx *ctx)
                                   "still alive; destroy them first", ctx->live_objects);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->own_stream)
-        (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
 }
@@ -310,6 +305,24 @@ extern "C" int klmi_butter2_lowpass(double wn, double b[3], double a[3])
     if (!(wn > 0. && wn < 1.))
         return fail(KLMI_E_ARG, "klmi_butter2_lowpass: Wn must lie in (0, 1), got %g", wn);
     butter2(wn, b, a);
+    return 0;
+}
+
+extern "C" int klmi_low_pass_coefficients(double frequency, double b[1], double a[2])
+{
+    if (!b || !a || !(frequency >= 0.))
+        return fail(KLMI_E_ARG, "klmi_low_pass_coefficients: frequency must be >= 0");
+    a[0] = 1.;
+    if (frequency == 0.) {
+        b[0] = 0.;
+        a[1] = -1.;
+    } else if (std::isinf(frequency)) {
+        b[0] = 1.;
+        a[1] = 0.;
+    } else {
+        a[1] = -std::exp(-kTau * frequency / kSampleRate);
+        b[0] = 1. - std::fabs(a[1]);
+    }
     return 0;
 }
 
@@ -388,6 +401,7 @@ struct klmi_bank {
 
     // scratch
     DevBuf<float> partial, dev_mix, dev_voices_f32;
+    DevBuf<double> stage;  // bus reduction, slice sums
     DevBuf<double> dev_voices_f64, ext_input, bus_f64;
     int ext_blocks = 0;   // blocks supplied by klmi_bank_set_input
     int ext_cursor = 0;   // blocks of it consumed by renders so far
@@ -899,8 +913,6 @@ template <int MODE> static size_t smem_bytes()
     using TT = TileTraits<MODE>;
     const int planes = TT::planes ? TT::planes : 1;
     size_t bytes = sizeof(typename TT::T) * (size_t)kWavesPerGroup * planes * TT::chunk * TT::stride;
-    if (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO)
-        bytes += sizeof(float) * (size_t)kWavesPerGroup * TT::planes * TT::chunk;
     return bytes;
 }
 
@@ -988,30 +1000,37 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix)
     hipStream_t st = b->ctx->stream;
     const int planes = b->desc.stereo ? 2 : 1;
     const int groups = (b->n + kGroup - 1) / kGroup;
-    // blocks per launch: keep the per-group partial buses within ~64 MiB
-    const size_t per_block = (size_t)groups * planes * kBlock * sizeof(float);
-    int bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, ((size_t)64 << 20) / per_block));
-    HIP_TRY(b->partial.reserve((size_t)groups * planes * kBlock * bpl));
+    // one partial bus per wave (64 voices); blocks per launch keep them within 256 MiB
+    const int rows = groups * kWavesPerGroup;
+    const int slices = bus_slices(rows);
+    const size_t per_block = (size_t)rows * planes * kBlock * sizeof(float);
+    int bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, ((size_t)256 << 20) / per_block));
+    HIP_TRY(b->partial.reserve((size_t)rows * planes * kBlock * bpl));
+    HIP_TRY(b->stage.reserve((size_t)slices * planes * kBlock * bpl));
     BankView view = make_view(b);
     b->timed_launches = 0;
     for (int base = 0; base < n_blocks; base += bpl) {
         const int nb = std::min(bpl, n_blocks - base);
         TRY(timing_begin(b, b->timed_launches));
-        hipError_t e =
-            b->desc.stereo
-                ? dispatch_voice<OUT_MIX_STEREO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
-                                                 b->n, base, b->block_clock + (uint32_t)base, nb, 0,
-                                                 b->partial.p, nullptr)
-                : dispatch_voice<OUT_MIX_MONO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
+        hipError_t e;
+        if (b->desc.stereo)
+            e = dispatch_voice<OUT_MIX_STEREO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
                                                b->n, base, b->block_clock + (uint32_t)base, nb, 0,
-                                                 b->partial.p, nullptr);
+                                               b->partial.p, nullptr);
+        else
+            e = dispatch_voice<OUT_MIX_MONO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
+                                             b->n, base, b->block_clock + (uint32_t)base, nb, 0,
+                                             b->partial.p, nullptr);
         if (e != hipSuccess)
             return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
         HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
         b->timed_launches++;
         const size_t bus_len = (size_t)nb * planes * kBlock;
-        hipLaunchKernelGGL(bus_reduce_kernel, dim3((unsigned)((bus_len + 255) / 256)), dim3(256), 0,
-                           st, b->partial.p, groups, bus_len, b->mix_divisor,
+        hipLaunchKernelGGL(bus_slice_kernel, dim3((unsigned)((bus_len + 1023) / 1024), slices),
+                           dim3(256), 0, st, b->partial.p, rows, bus_len, b->stage.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bus_finish_kernel, dim3((unsigned)((bus_len + 255) / 256)), dim3(256), 0,
+                           st, b->stage.p, slices, bus_len, b->mix_divisor,
                            dev_mix + (size_t)base * planes * kBlock);
         HIP_TRY(hipGetLastError());
     }

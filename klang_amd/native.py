@@ -35,7 +35,7 @@ EVENT_DTYPE = np.dtype([('voice', '<u4'), ('block', '<u4'), ('kind', '<u4'), ('r
 EXPORTS = [
     'klmi_last_error', 'klmi_version', 'klmi_ctx_create', 'klmi_ctx_destroy',
     'klmi_ctx_synchronize', 'klmi_filter_grid', 'klmi_filter_grid_index', 'klmi_butter2_lowpass',
-    'klmi_envelope_coefficients', 'klmi_panning_amplitudes', 'klmi_reverb_design',
+    'klmi_envelope_coefficients', 'klmi_low_pass_coefficients', 'klmi_panning_amplitudes', 'klmi_reverb_design',
     'klmi_bank_create', 'klmi_bank_destroy', 'klmi_bank_set_params', 'klmi_bank_state_get',
     'klmi_bank_state_set', 'klmi_bank_events', 'klmi_bank_set_mix_divisor', 'klmi_bank_set_input',
     'klmi_bank_render', 'klmi_bank_render_device', 'klmi_bank_render_voices',
@@ -79,6 +79,7 @@ def load():
     L.klmi_filter_grid_index.argtypes = [C.c_double]
     L.klmi_butter2_lowpass.argtypes = [C.c_double, _dp, _dp]
     L.klmi_envelope_coefficients.argtypes = [C.c_double] * 6 + [_dp]
+    L.klmi_low_pass_coefficients.argtypes = [C.c_double, _dp, _dp]
     L.klmi_panning_amplitudes.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, _dp]
     L.klmi_reverb_design.argtypes = [C.c_double, C.c_double, C.c_int, _ip, _dp]
     L.klmi_bank_create.argtypes = [_vp, C.c_int, C.POINTER(ChainDesc), C.POINTER(_vp)]
@@ -151,6 +152,13 @@ def butter2_lowpass(wn):
     b, a = np.empty(3), np.empty(3)
     _check(load().klmi_butter2_lowpass(float(wn), _p(b), _p(a)))
     return b, a
+
+
+def low_pass_coefficients(frequency):
+    """Single-pole low-pass (b, a) as lists, like effects.py:33-55."""
+    b, a = np.empty(1), np.empty(2)
+    _check(load().klmi_low_pass_coefficients(float(frequency), _p(b), _p(a)))
+    return [float(b[0])], [float(a[0]), float(a[1])]
 
 
 def envelope_coefficients(attack, decay, sustain, release, dt, overshoot=1e-3):

@@ -42,6 +42,11 @@ def test_host_helpers_against_reference_fixtures(golden):
         np.testing.assert_allclose(np.r_[b, a], g['table'][i], rtol=4e-15, atol=1e-15)
     for req, want in zip(g['index_requests'], g['index_results']):
         assert native.filter_grid_index(req) == want
+    for f, (b0, a1) in zip(g['one_pole_freqs'], g['one_pole_coeffs']):
+        b, a = native.low_pass_coefficients(f)
+        assert abs(b[0] - b0) <= 2e-16 and abs(a[1] - a1) <= 2e-16 and a[0] == 1.
+    assert native.low_pass_coefficients(0.) == ([0.], [1., -1.])
+    assert native.low_pass_coefficients(float('inf')) == ([1.], [1., 0.])
     r = golden('reverb')
     taps, alphas = native.reverb_design(3., .03, 10)
     np.testing.assert_array_equal(taps, r['taps_default'])

@@ -460,6 +460,27 @@ def test_full_size_config3_properties(hip, ctx, oracle):
     np.testing.assert_array_equal(full.get_state(hip.F_PHASE), ob.phase)
 
 
+def test_render_device_is_ordered_on_the_callers_stream(hip, ctx):
+    """klmi_ctx_create(stream=NULL) is the default stream: a torch copy issued
+    right after render_device, with no synchronisation in between, sees the bus."""
+    import torch
+    patch = P.polyphonic_saw_patch(n_voices=20000, n_blocks=64, off_base=20, off_span=30)
+    want = hip_bank_from_patch(hip, ctx, patch).render(64)
+    for side in (False, True):
+        stream = torch.cuda.Stream() if side else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            c2 = hip.Context(0, stream.cuda_stream)
+            bank = hip_bank_from_patch(hip, c2, patch)
+            bus = torch.zeros((64, 1, B), dtype=torch.float32, device='cuda')
+            host = torch.zeros((64, 1, B), dtype=torch.float32).pin_memory()
+            bank.render_device(64, bus.data_ptr())
+            host.copy_(bus, non_blocking=True)
+            stream.synchronize()
+            np.testing.assert_array_equal(host.numpy(), want)
+            bank.close()
+            c2.close()
+
+
 def test_preview_leaves_state_and_queue_untouched(hip, ctx):
     patch = P.polyphonic_saw_patch(n_voices=300, n_blocks=12, off_base=3, off_span=6)
     a = hip_bank_from_patch(hip, ctx, patch)
