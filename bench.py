@@ -35,8 +35,9 @@ B = 256
 # params 80 B + 2 x state 36 B per voice per 256-sample block, + 4 B/N bus
 ALGO_BYTES_PER_VOICE_SAMPLE = 152. / 256.
 HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
-F64_OPS_PER_VOICE_SAMPLE = 30.
-F64_NONFMA_PEAK = 39.3e12
+# VALU issue roof: 256 CUs x 4 SIMDs, one 64-lane float64 instruction per 4 cycles at 2.4 GHz
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.          # wave-instructions/s (= 39.3e12 lane-ops/s / 64)
+VALU_INSTR_PER_VOICE_SAMPLE = 24.2              # SQ_INSTS_VALU per wave-sample (profiles/), fallback
 
 
 def cpu_baseline(n_voices, log):
@@ -157,11 +158,15 @@ def main():
         per_launch_units = VOICES_PER_GPU * BLOCKS_PER_STEP * B / max(launches, 1)
         avg_launch_s = (sum(kernel_ms) / len(kernel_ms)) / max(launches, 1) * 1e-3
         achieved = ALGO_BYTES_PER_VOICE_SAMPLE * per_launch_units / avg_launch_s / 1e9
-        traffic = None
+        traffic, valu_instr = None, VALU_INSTR_PER_VOICE_SAMPLE
         tfile = os.path.join(ROOT, 'profiles', 'traffic_voice_kernel.json')
         if os.path.exists(tfile):
             with open(tfile) as fh:
-                traffic = json.load(fh).get('hbm_bytes_per_launch')
+                prof = json.load(fh)
+            # PMC results of tools/profile_bench.sh for this same workload (per launch)
+            if prof.get('voice_samples_per_launch') == per_launch_units:
+                traffic = prof.get('hbm_bytes_per_launch')
+                valu_instr = prof.get('valu_instructions_per_voice_sample', valu_instr)
         result = {
             'metric': 'voice-samples/sec (osc+ADSR+biquad)', 'value': value,
             'unit': 'voice-samples/s', 'n_gpus': world, 'steps': args.steps,
@@ -183,10 +188,14 @@ def main():
                 'kernel': 'voice_kernel<env,biquad,mix_mono>', 'launches_per_step': launches,
                 'avg_launch_ms': avg_launch_s * 1e3,
                 'algorithmic_bytes_per_voice_sample': ALGO_BYTES_PER_VOICE_SAMPLE,
-                'note': 'fused path is float64-VALU bound, not HBM bound (SURVEY 8d); '
-                        'valu_frac = voice-samples/s x 30 non-FMA f64 ops / 39.3e12',
-                'valu_frac': (per_launch_units / avg_launch_s) * F64_OPS_PER_VOICE_SAMPLE
-                             / F64_NONFMA_PEAK,
+                'note': 'fused path is float64-VALU-issue bound, not HBM bound (SURVEY 8d): state '
+                        'stays in registers for the whole launch, so measured traffic is below the '
+                        'per-block algorithmic bytes.  valu_frac = wave-instructions/s (voice-samples/s '
+                        '/ 64 x measured VALU instructions per wave-sample) / (1024 SIMDs x 0.6e9 '
+                        'issue slots/s); the measured float64 issue ceiling is ~0.85 of that '
+                        '(profiles/r01_ubench_f64_issue.txt)',
+                'valu_instructions_per_voice_sample': valu_instr,
+                'valu_frac': (per_launch_units / avg_launch_s) / 64. * valu_instr / VALU_ISSUE_PEAK,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
