@@ -88,19 +88,47 @@ typedef enum {
                                (effects.py:271-274, 365-369) */
     KLMI_F_GAIN = 12,       /* Mixer.gains[i] (mixer.py:33,43-44) */
     KLMI_F_PAN = 13,        /* StereoMixer.pannings[i] (mixer.py:88,97-99) */
+    /* the voice's cutoff Lfo (desc.cutoff_lfo): Lfo(frequency, wave_func, shape=1,
+     * outputRange) | Filter.frequency (oscillators.py:143-181, effects.py:365-373);
+     * scale / offset = linear_mapping((-1, 1), outputRange) (oscillators.py:171) */
+    KLMI_F_LFO_FREQUENCY = 14,
+    KLMI_F_LFO_WAVE = 15,   /* klmi_wave, sine .. triangle */
+    KLMI_F_LFO_SCALE = 16,
+    KLMI_F_LFO_OFFSET = 17,
+    /* the voice's audio-rate modulator (desc.mod_target): FmOscillator.modulator +
+     * intensity (oscillators.py:202-220) or an Lfo(shape=256) (oscillators.py:178-181) */
+    KLMI_F_MOD_FREQUENCY = 18,
+    KLMI_F_MOD_WAVE = 19,   /* klmi_wave, sine .. triangle */
+    KLMI_F_MOD_SCALE = 20,  /* FM: intensity; Lfo: scale */
+    KLMI_F_MOD_OFFSET = 21, /* Lfo: offset (unused by FM) */
     /* state */
     KLMI_F_PHASE = 32,        /* Phasor.currentPhase (oscillators.py:89) */
     KLMI_F_ENV_VALUE = 33,    /* _envelope.c:147 */
     KLMI_F_ENV_STAGE = 34,    /* _envelope.c:146 (klmi_stage) */
     KLMI_F_ENV_ENABLED = 35,  /* _envelope.c:148 */
     KLMI_F_Z0 = 36,           /* _Filter.state[0] (effects.py:305-316) */
-    KLMI_F_Z1 = 37            /* _Filter.state[1] */
+    KLMI_F_Z1 = 37,           /* _Filter.state[1] */
+    KLMI_F_LFO_PHASE = 38,    /* the cutoff Lfo's currentPhase */
+    KLMI_F_MOD_PHASE = 39     /* the modulator's currentPhase */
 } klmi_field;
+
+/* Audio-rate modulation input of the voice's oscillator (one modulator per voice). */
+typedef enum {
+    KLMI_MOD_NONE = 0,
+    KLMI_MOD_FM = 1,         /* FmOscillator: wave(phase + intensity * modulator)
+                                (oscillators.py:193-234) */
+    KLMI_MOD_FREQUENCY = 2,  /* Lfo(shape=256) | Oscillator.frequency: array branch of
+                                sample_phase (oscillators.py:61-64) */
+    KLMI_MOD_DUTY = 3        /* Lfo(shape=256) | PwmOscillator.dutyCycle
+                                (oscillators.py:256-260) */
+} klmi_mod_target;
 
 /* What one bank evaluates per voice, in the reference's terms:
  *   osc = Oscillator(wave_func)                     oscillators.py:111-140
+ *         (mod_target: FmOscillator / modulated frequency / modulated duty cycle)
  *   x   = has_env ? (amplitude*osc)*ADSR/AR/D/R     voices.py:66-74, envelopes.py:18-114
  *   x   = has_filter ? Filter(x)                    effects.py:342-385
+ *         (cutoff_lfo: Filter.frequency driven per buffer by the voice's own Lfo)
  *   x   = has_reverb ? Reverb(x)                    effects.py:564-615
  *   bus = stereo ? StereoMixer : Mixer over voices  mixer.py:15-104
  */
@@ -116,6 +144,8 @@ typedef struct {
     double reverb_pre_delay;  /* preDelay (s) */
     double reverb_dry_wet;    /* dryWet, clipped to [0,1] (effects.py:586) */
     int32_t reverb_n_echos;   /* nEchos > 0 */
+    int32_t cutoff_lfo;       /* 1: Lfo(shape=1) | Filter.frequency per voice (needs has_filter) */
+    int32_t mod_target;       /* klmi_mod_target */
     int32_t reserved;
 } klmi_chain_desc;
 

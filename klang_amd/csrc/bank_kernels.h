@@ -12,9 +12,6 @@
 #include "dsp_device.h"
 #include <type_traits>
 
-#ifndef KLMI_GROUP
-#define KLMI_GROUP 8
-#endif
 namespace klmi {
 
 // t[n] = DT * n, n = 0..256 (helpers.py:27-32), padded to whole groups of 8
@@ -47,7 +44,20 @@ struct BankView {
     uint32_t *ev_cursor;        // [n] progress through the voice's events
     // external input [span][n] (time-major) for W_EXTERNAL voices
     const double *ext_input;
+    // modulation inputs; null / 0 when the bank has none
+    const double *lfo_par;     // [3][n]: frequency, scale, offset of the cutoff Lfo
+    const int32_t *lfo_wave;
+    double *lfo_phase;         // state
+    const double *grid;        // [1000] filter grid frequencies
+    int mod_target;            // ModTarget
+    const double *mod_par;     // [3][n]: frequency, scale (FM: intensity), offset
+    const int32_t *mod_wave;
+    double *mod_phase;         // state
 };
+
+enum ModTarget : int { MT_NONE = 0, MT_FM = 1, MT_FREQUENCY = 2, MT_DUTY = 3 };
+constexpr int kGridPoints = 1000;
+constexpr double kInterval = kDt * kBlock;  // klang/audio/helpers.py:12
 
 enum OutMode : int {
     OUT_MIX_MONO = 0,    // partial bus per workgroup
@@ -86,6 +96,93 @@ __device__ __forceinline__ float row_sum64(const float *row)
         for (int j = 0; j < w; ++j)
             s[j] = s[j] + s[j + w];
     return s[0];
+}
+
+// One sample of one voice into the wave's tile (or straight to the time-major bus).
+template <int MODE, bool UNIT = false>
+__device__ __forceinline__ void emit_sample(typename TileTraits<MODE>::T *tile, int i, int lane,
+                                            double x, double gl, double gr, bool live, void *out,
+                                            int s0, int count, int local)
+{
+    using TT = TileTraits<MODE>;
+    if constexpr (MODE == OUT_MIX_MONO) {
+        tile[i * TT::stride + lane] = UNIT ? (float)x : (float)(gl * x);
+    } else if constexpr (MODE == OUT_MIX_STEREO) {
+        tile[i * TT::stride + lane] = (float)(gl * x);
+        tile[(TT::chunk + i) * TT::stride + lane] = (float)(gr * x);
+    } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
+        tile[i * TT::stride + lane] = (typename TT::T)x;
+    } else {
+        if (live)
+            reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
+    }
+}
+
+// End of a chunk of TT::chunk samples: the tile leaves the wave.
+//   mix modes: lane = sample, sum the 64 voices of this wave; one partial row per WAVE,
+//              so the waves of a workgroup never wait for each other
+//   voices:    lane = sample, 64 voice rows of TT::chunk contiguous samples each
+template <int MODE>
+__device__ __forceinline__ void flush_chunk(typename TileTraits<MODE>::T *tile, int lane, int wave,
+                                            int b, int c, int n_blocks, int count, int span_total,
+                                            int s0, float *__restrict__ partial,
+                                            void *__restrict__ out)
+{
+    using TT = TileTraits<MODE>;
+    using T = typename TT::T;
+    constexpr int CH = TT::chunk;
+    constexpr int PLANES = TT::planes;
+    // the tile is wave-private: LDS operations of one wave execute in order;
+    // the fence only stops the compiler from moving them across this point
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+            for (int r = lane; r < CH; r += 64) {
+                const size_t o = ((size_t)b * PLANES + pl) * kBlock + c * CH + r;
+                partial[(size_t)(blockIdx.x * kWavesPerGroup + wave) * n_blocks * PLANES * kBlock + o] =
+                    row_sum64(tile + (size_t)(pl * CH + r) * TT::stride);
+            }
+        }
+    } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
+        T *o = reinterpret_cast<T *>(out);
+        const int base_local = blockIdx.x * kGroup + wave * 64;
+        for (int j = 0; j < 64; ++j) {
+            if (base_local + j < count) {
+                for (int r = lane; r < CH; r += 64)
+                    o[(size_t)(base_local + j) * span_total + s0 + r] = tile[r * TT::stride + j];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Lfo(shape=1) | Filter.frequency, once per block (oscillators.py:175-181,
+// effects.py:271-274, 365-373): value = scale * wave(phase) + offset; the phasor steps
+// by TAU*f*INTERVAL; row = searchsorted(grid, value) clipped to the last row.
+__device__ __forceinline__ void lfo_cutoff_step(const BankView &bk, int v, double &lfo_ph,
+                                                int &coef_row, Biquad &bq)
+{
+    const size_t n = (size_t)bk.n;
+    const double f = bk.lfo_par[v], scale = bk.lfo_par[n + v], offset = bk.lfo_par[2 * n + v];
+    const double value = scale * wave_eval_any(bk.lfo_wave[v], lfo_ph, kPi) + offset;
+    lfo_ph = np_mod_tau(kTau * f * kInterval + lfo_ph);
+    int lo = 0, hi = kGridPoints;  // first row whose frequency is >= value
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bk.grid[mid] < value)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const int row = lo < kGridPoints - 1 ? lo : kGridPoints - 1;
+    if (row != coef_row) {
+        coef_row = row;
+        const double *c = bk.coef_table + 5 * (size_t)row;
+        bq.b0 = c[0], bq.b1 = c[1], bq.b2 = c[2], bq.a1 = c[3], bq.a2 = c[4];
+    }
 }
 
 // grid.x = ceil(count / 256) workgroups of 4 waves.
@@ -158,6 +255,9 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
         bq.z1 = bk.z1[v];
     }
 
+    const bool cutoff_lfo = FILT && bk.lfo_par != nullptr;  // uniform over the launch
+    double lfo_ph = cutoff_lfo ? bk.lfo_phase[v] : 0.;
+
     double gl = 0., gr = 0.;
     bool unit_gain = false;  // wave-uniform: every live lane's gain is exactly 1 (plain Mixer)
     if (MIX) {
@@ -199,6 +299,9 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             next_ev = (ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
         }
 
+        if (cutoff_lfo)
+            lfo_cutoff_step(bk, v, lfo_ph, coef_row, bq);
+
         const double omega = kTau * freq;  // oscillators.py:60  (TAU * frequency) * t
         const double start = phase;
         // wave-uniform: may this block use the fast remainder?
@@ -218,12 +321,8 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                 // 8 time points per scalar load (wave-uniform index).  Fetching them a group
                 // ahead was measured slower (more scalar registers live across the group).
                 const Time8 *times = reinterpret_cast<const Time8 *>(c_time) + ((c * CH) >> 3);
-                auto group8 = [&](int i8, const Time8 *tp) {
-                    constexpr int G = KLMI_GROUP;
-                    Time8 tt[G / 8];
-#pragma unroll
-                    for (int q = 0; q < G / 8; ++q)
-                        tt[q] = tp[q];
+                auto group8 = [&](int i8, const Time8 &tt) {
+                    constexpr int G = 8;
                     const int wsel = (WK >= 0) ? WK : wave_id;
                     // Eight samples as ONE straight-line region: oscillator (8 independent
                     // samples), envelope and biquad recurrences (serial chains) are all
@@ -254,7 +353,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                         uint32_t hi_max = 0;
 #pragma unroll
                         for (int j = 0; j < G; ++j) {
-                            arg[j] = omega * tt[j >> 3].t[j & 7] + start;  // oscillators.py:60
+                            arg[j] = omega * tt.t[j] + start;  // oscillators.py:60
                             if constexpr (FAST) {
                                 const double k = floor(arg[j] * kInvTau);
                                 const double ph = __builtin_fma(-k, kTau, arg[j]);
@@ -316,27 +415,13 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                     }
 
                     // -- output ----------------------------------------------------------------
-                    {
 #pragma unroll
-                        for (int j = 0; j < G; ++j) {
-                            const int i = i8 + j;
-                            const double x = y[j];
-                            if constexpr (MODE == OUT_MIX_MONO) {
-                                tile[i * TT::stride + lane] = UNIT ? (float)x : (float)(gl * x);
-                            } else if constexpr (MODE == OUT_MIX_STEREO) {
-                                tile[i * TT::stride + lane] = (float)(gl * x);
-                                tile[(CH + i) * TT::stride + lane] = (float)(gr * x);
-                            } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
-                                tile[i * TT::stride + lane] = (T)x;
-                            } else {
-                                if (live)
-                                    reinterpret_cast<double *>(out)[(size_t)(s0 + i) * count + local] = x;
-                            }
-                        }
-                    }
+                    for (int j = 0; j < G; ++j)
+                        emit_sample<MODE, UNIT>(tile, i8 + j, lane, y[j], gl, gr, live, out, s0, count,
+                                                local);
                 };
-                for (int i8 = 0; i8 < CH; i8 += KLMI_GROUP)
-                    group8(i8, times + (i8 >> 3));
+                for (int i8 = 0; i8 < CH; i8 += 8)
+                    group8(i8, times[i8 >> 3]);
             };
             using std::integral_constant;
             using Fast = std::true_type;
@@ -362,36 +447,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             } else {
                 dispatch(std::false_type{});
             }
-            // the tile is wave-private: LDS operations of one wave execute in order;
-            // the fence only stops the compiler from moving them across this point
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-
-            if constexpr (MIX) {
-                // lane = sample: sum the 64 voices of this wave; one partial row per WAVE,
-                // so the waves of a workgroup never wait for each other
-#pragma unroll
-                for (int pl = 0; pl < PLANES; ++pl) {
-                    for (int r = lane; r < CH; r += 64) {
-                        const size_t o = ((size_t)b * PLANES + pl) * kBlock + c * CH + r;
-                        partial[(size_t)(blockIdx.x * kWavesPerGroup + wave) * n_blocks * PLANES * kBlock + o] =
-                            row_sum64(tile + (size_t)(pl * CH + r) * TT::stride);
-                    }
-                }
-            } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
-                // lane = sample: write 64 voice rows, CH contiguous samples each
-                T *o = reinterpret_cast<T *>(out);
-                const int base_local = blockIdx.x * kGroup + wave * 64;
-                for (int j = 0; j < 64; ++j) {
-                    if (base_local + j < count) {
-                        for (int r = lane; r < CH; r += 64)
-                            o[(size_t)(base_local + j) * span_total + s0 + r] =
-                                tile[r * TT::stride + j];
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
         }
         // oscillators.py:66-67: next start phase is sample 256 of this block
         if (wave_id != W_EXTERNAL && wave_id != W_ONE)
@@ -411,6 +467,8 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             bk.z0[v] = bq.z0;
             bk.z1[v] = bq.z1;
             bk.coef_index_rw[v] = coef_row;
+            if (cutoff_lfo)
+                bk.lfo_phase[v] = lfo_ph;
         }
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
     }

@@ -142,6 +142,31 @@ __device__ __forceinline__ double wave_eval(int wave, double p, double duty_edge
     }
 }
 
+// The wave functions for ANY phase argument (FmOscillator evaluates them at
+// phase + intensity * modulator, oscillators.py:220; an Lfo's first phase is whatever
+// startPhase was given): math.py:9-11 wrap = np.mod(p + PI, TAU) - PI.
+__device__ __forceinline__ double wave_eval_any(int wave, double p, double duty_edge)
+{
+    switch (wave) {
+    case W_SINE:
+        return (p >= 0. && p <= kTau) ? sin_wrapped(p) : sin(p);
+    case W_SQUARE:
+        return (np_mod_tau(p + kPi) - kPi >= 0.) ? 1. : -1.;
+    case W_SAWTOOTH:
+        return div_pi(np_mod_tau(p)) - 1.;
+    case W_TRIANGLE: {
+        const double w = np_mod_tau(p + kPi) - kPi;
+        double q = div_tau(4. * w);
+        q = q < 0. ? q + 4. : q;
+        return 1. - fabs(q - 2.);
+    }
+    case W_PWM:
+        return (p < duty_edge) ? 1. : -1.;
+    default:
+        return 1.;
+    }
+}
+
 // _envelope.c state machine with the per-stage recurrence held in registers.
 // OFF and SUSTAINING use coef 0: base + value*0 == base exactly.
 struct EnvParams {

@@ -17,6 +17,7 @@
 
 #include "aux_kernels.h"
 #include "bank_kernels.h"
+#include "mod_kernels.h"
 #include "reverb_kernels.h"
 
 using namespace klmi;
@@ -199,7 +200,7 @@ struct klmi_ctx {
     int n_cus = 256;                 // compute units of the device
     std::vector<double> grid;        // 1000 frequencies
     std::vector<double> table;       // [1000][5] b0 b1 b2 a1 a2
-    DevBuf<double> d_table;
+    DevBuf<double> d_table, d_grid;
 };
 
 static int use(klmi_ctx *ctx)
@@ -248,6 +249,11 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
     for (int n = 0; n < kTimeSlots; ++n)
         t[n] = kDt * (double)n;  // helpers.py:30  dt * np.arange(length)
     hipError_t e = ctx->d_table.alloc(ctx->table.size());
+    if (e == hipSuccess)
+        e = ctx->d_grid.alloc(ctx->grid.size());
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->d_grid.p, ctx->grid.data(), ctx->grid.size() * sizeof(double),
+                      hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(ctx->d_table.p, ctx->table.data(), ctx->table.size() * sizeof(double),
                       hipMemcpyHostToDevice);
@@ -383,8 +389,10 @@ struct klmi_bank {
     DevBuf<double> duty, env_coef, gain_l, gain_r;
     DevBuf<int32_t> wave;
     DevBuf<uint32_t> env_flags;
+    DevBuf<double> lfo_par, mod_par;    // [3][n] frequency, scale, offset (allocated when used)
+    DevBuf<int32_t> lfo_wave, mod_wave;
     // device state: one slab so that a preview can snapshot/restore it with two copies
-    //   f64: phase | env_value | z0 | z1 | frequency | amplitude     (6n)
+    //   f64: phase | env_value | z0 | z1 | frequency | amplitude | lfo phase | mod phase  (8n)
     //   u32: env_state | coef_index | ev_cursor                       (3n)
     DevBuf<double> state_f64, backup_f64;
     DevBuf<uint32_t> state_u32, backup_u32;
@@ -425,7 +433,7 @@ struct klmi_bank {
     uint32_t *u32(int slot) { return state_u32.p + (size_t)slot * n; }
 };
 
-enum { SL_PHASE = 0, SL_ENV_VALUE, SL_Z0, SL_Z1, SL_FREQ, SL_AMP, SL_F64_COUNT };
+enum { SL_PHASE = 0, SL_ENV_VALUE, SL_Z0, SL_Z1, SL_FREQ, SL_AMP, SL_LFO_PHASE, SL_MOD_PHASE, SL_F64_COUNT };
 enum { SL_ENV_STATE = 0, SL_COEF_INDEX, SL_EV_CURSOR, SL_U32_COUNT };
 
 static BankView make_view(klmi_bank *b)
@@ -455,6 +463,14 @@ static BankView make_view(klmi_bank *b)
     v.ev_velocity = b->ev_velocity.p;
     v.ev_frequency = b->ev_frequency.p;
     v.ext_input = b->ext_input.p ? b->ext_input.p + (size_t)b->ext_cursor * kBlock * b->n : nullptr;
+    v.lfo_par = b->lfo_par.p;
+    v.lfo_wave = b->lfo_wave.p;
+    v.lfo_phase = b->f64(SL_LFO_PHASE);
+    v.grid = b->ctx->d_grid.p;
+    v.mod_target = b->desc.mod_target;
+    v.mod_par = b->mod_par.p;
+    v.mod_wave = b->mod_wave.p;
+    v.mod_phase = b->f64(SL_MOD_PHASE);
     return v;
 }
 
@@ -526,6 +542,10 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         return fail(KLMI_E_ARG, "Invalid panning mode %d!", desc->pan_mode);
     if (desc->has_pan_law && desc->pan_law > 0)
         return fail(KLMI_E_ARG, "Pan law has to be negative!");
+    if (desc->cutoff_lfo && !desc->has_filter)
+        return fail(KLMI_E_ARG, "klmi_bank_create: cutoff_lfo needs has_filter");
+    if (desc->mod_target < KLMI_MOD_NONE || desc->mod_target > KLMI_MOD_DUTY)
+        return fail(KLMI_E_ARG, "klmi_bank_create: unknown mod_target %d", desc->mod_target);
     klmi_bank *b = new klmi_bank;
     b->ctx = ctx;
     b->n = n_voices;
@@ -558,6 +578,14 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     chk(b->state_u32.alloc(SL_U32_COUNT * n));
     chk(b->backup_f64.alloc(SL_F64_COUNT * n));
     chk(b->backup_u32.alloc(SL_U32_COUNT * n));
+    if (desc->cutoff_lfo) {
+        chk(b->lfo_par.alloc(3 * n));
+        chk(b->lfo_wave.alloc(n));
+    }
+    if (desc->mod_target != KLMI_MOD_NONE) {
+        chk(b->mod_par.alloc(3 * n));
+        chk(b->mod_wave.alloc(n));
+    }
     chk(b->ev_offset.alloc(n + 1));
     chk(b->ev_block.alloc(1));
     chk(b->ev_kind.alloc(1));
@@ -583,6 +611,20 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     step(fill_device<double>(b, b->f64(SL_FREQ), n, 440.));   // oscillators.py:121
     step(fill_device<uint32_t>(b, b->u32(SL_COEF_INDEX), n,
                                (uint32_t)grid_index(ctx->grid.data(), 440.)));
+    if (desc->cutoff_lfo) {
+        // Lfo defaults (oscillators.py:156-157): 1 Hz, sine, outputRange (0, 1)
+        step(fill_device<double>(b, b->lfo_par.p, n, 1.));
+        step(fill_device<double>(b, b->lfo_par.p + n, n, .5));
+        step(fill_device<double>(b, b->lfo_par.p + 2 * n, n, .5));
+        step(fill_device<int32_t>(b, b->lfo_wave.p, n, KLMI_WAVE_SINE));
+    }
+    if (desc->mod_target != KLMI_MOD_NONE) {
+        // FmOscillator defaults (oscillators.py:202-203): modFrequency 10 Hz, intensity 1, sine
+        step(fill_device<double>(b, b->mod_par.p, n, 10.));
+        step(fill_device<double>(b, b->mod_par.p + n, n, 1.));
+        step(fill_device<double>(b, b->mod_par.p + 2 * n, n, 0.));
+        step(fill_device<int32_t>(b, b->mod_wave.p, n, KLMI_WAVE_SINE));
+    }
     if (rc == 0)
         step(upload_env(b, 0, n_voices));
     if (rc == 0)
@@ -652,6 +694,8 @@ static int state_slot(int field, bool *is_u32)
     case KLMI_F_Z1: return SL_Z1;
     case KLMI_F_FREQUENCY: return SL_FREQ;
     case KLMI_F_AMPLITUDE: return SL_AMP;
+    case KLMI_F_LFO_PHASE: return SL_LFO_PHASE;
+    case KLMI_F_MOD_PHASE: return SL_MOD_PHASE;
     case KLMI_F_ENV_STAGE:
     case KLMI_F_ENV_ENABLED: *is_u32 = true; return SL_ENV_STATE;
     default: return -1;
@@ -728,6 +772,42 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
         for (int i = 0; i < count; ++i)
             idx[i] = grid_index(b->ctx->grid.data(), host[i]);
         HIP_TRY(hipMemcpyAsync(b->u32(SL_COEF_INDEX) + first, idx.data(), sizeof(int32_t) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    case KLMI_F_LFO_FREQUENCY:
+    case KLMI_F_LFO_SCALE:
+    case KLMI_F_LFO_OFFSET:
+    case KLMI_F_MOD_FREQUENCY:
+    case KLMI_F_MOD_SCALE:
+    case KLMI_F_MOD_OFFSET: {
+        const bool lfo = field <= KLMI_F_LFO_OFFSET;
+        DevBuf<double> &par = lfo ? b->lfo_par : b->mod_par;
+        if (!par.p)
+            return fail(KLMI_E_STATE, "klmi_bank_set_params: the bank was created without %s",
+                        lfo ? "cutoff_lfo" : "a mod_target");
+        const int base = lfo ? KLMI_F_LFO_FREQUENCY : KLMI_F_MOD_FREQUENCY;
+        const int row = field == base ? 0 : field - base - 1;  // FREQUENCY, (WAVE), SCALE, OFFSET
+        HIP_TRY(hipMemcpyAsync(par.p + (size_t)row * b->n + first, host, sizeof(double) * count,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return 0;
+    }
+    case KLMI_F_LFO_WAVE:
+    case KLMI_F_MOD_WAVE: {
+        DevBuf<int32_t> &dst = field == KLMI_F_LFO_WAVE ? b->lfo_wave : b->mod_wave;
+        if (!dst.p)
+            return fail(KLMI_E_STATE, "klmi_bank_set_params: the bank was created without %s",
+                        field == KLMI_F_LFO_WAVE ? "cutoff_lfo" : "a mod_target");
+        std::vector<int32_t> w(count);
+        for (int i = 0; i < count; ++i) {
+            if (!(host[i] >= 0. && host[i] <= (double)KLMI_WAVE_TRIANGLE))
+                return fail(KLMI_E_ARG, "klmi_bank_set_params: modulator wave id %g (sine, square, "
+                                        "sawtooth, triangle are 0..3)", host[i]);
+            w[i] = (int32_t)host[i];
+        }
+        HIP_TRY(hipMemcpyAsync(dst.p + first, w.data(), sizeof(int32_t) * count,
                                hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         return 0;
@@ -939,11 +1019,38 @@ static hipError_t launch_voice(hipStream_t st, const BankView &view, int first, 
     return hipGetLastError();
 }
 
+// chains with an audio-rate modulation input: exact per-sample kernel (mod_kernels.h)
+template <int MODE>
+static hipError_t launch_mod(bool env, bool filt, hipStream_t st, const BankView &view, int first,
+                             int count, int block_base, uint32_t clock_base, int n_blocks,
+                             int span_total, float *partial, void *out)
+{
+    static bool configured[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t smem = smem_bytes<MODE>();
+    auto kernel = voice_mod_kernel<MODE>;
+    if (dev < 16 && !configured[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess)
+            return e;
+        configured[dev] = true;
+    }
+    const int groups = (count + kGroup - 1) / kGroup;
+    hipLaunchKernelGGL(kernel, dim3(groups), dim3(kGroup), smem, st, view, (int)env, (int)filt, first,
+                       count, block_base, clock_base, n_blocks, span_total, partial, out);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const BankView &view,
                                  int first, int count, int block_base, uint32_t clock_base,
                                  int n_blocks, int span_total, float *partial, void *out)
 {
+    if (view.mod_target != MT_NONE)
+        return launch_mod<MODE>(env, filt, st, view, first, count, block_base, clock_base, n_blocks,
+                                span_total, partial, out);
     if (env && filt)
         return launch_voice<true, true, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
                                               span_total, partial, out);

@@ -22,7 +22,11 @@ BUFFER_SIZE = 256
 # klmi_field
 F_FREQUENCY, F_AMPLITUDE, F_WAVE, F_DUTY, F_ATTACK, F_DECAY, F_SUSTAIN, F_RELEASE, F_OVERSHOOT, \
     F_LOOP, F_RETRIGGER, F_CUTOFF, F_GAIN, F_PAN = range(14)
-F_PHASE, F_ENV_VALUE, F_ENV_STAGE, F_ENV_ENABLED, F_Z0, F_Z1 = range(32, 38)
+F_LFO_FREQUENCY, F_LFO_WAVE, F_LFO_SCALE, F_LFO_OFFSET, F_MOD_FREQUENCY, F_MOD_WAVE, \
+    F_MOD_SCALE, F_MOD_OFFSET = range(14, 22)
+F_PHASE, F_ENV_VALUE, F_ENV_STAGE, F_ENV_ENABLED, F_Z0, F_Z1, F_LFO_PHASE, F_MOD_PHASE = \
+    range(32, 40)
+MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)   # klmi_mod_target
 
 WAVE_SINE, WAVE_SQUARE, WAVE_SAWTOOTH, WAVE_TRIANGLE, WAVE_PWM, WAVE_ONE, WAVE_EXTERNAL = range(7)
 EV_NOTE_OFF, EV_NOTE_ON, EV_SET_CUTOFF, EV_SET_FREQUENCY = range(4)
@@ -51,7 +55,8 @@ class ChainDesc(C.Structure):
                 ('stereo', C.c_int32), ('pan_mode', C.c_int32), ('has_pan_law', C.c_int32),
                 ('pan_law', C.c_double), ('reverb_decay', C.c_double),
                 ('reverb_pre_delay', C.c_double), ('reverb_dry_wet', C.c_double),
-                ('reverb_n_echos', C.c_int32), ('reserved', C.c_int32)]
+                ('reverb_n_echos', C.c_int32), ('cutoff_lfo', C.c_int32),
+                ('mod_target', C.c_int32), ('reserved', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -69,6 +74,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise KlangError('HIP library missing: %s (build it with `make -C klang_amd/csrc`); '
                          'klang_amd has no CPU fallback' % LIB_PATH)
+    # PyTorch's ROCm wheel bundles its own HIP runtime.  A process that uses both must load
+    # torch's first: with the library's runtime loaded first,
+    # whichever side initialises second finds no device.  torch is optional plumbing
+    # (sharding, stream hand-over); without it the library runs on the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.klmi_last_error.restype = C.c_char_p
     L.klmi_version.restype = C.c_char_p
@@ -251,12 +264,14 @@ class Bank:
     """Device-resident bank of independent voices (klmi_bank_*)."""
 
     def __init__(self, ctx, n_voices, has_env=True, has_filter=False, has_reverb=False,
-                 stereo=False, pan_mode='constant_power', pan_law=None, reverb=None):
+                 stereo=False, pan_mode='constant_power', pan_law=None, reverb=None,
+                 cutoff_lfo=False, mod_target=MOD_NONE):
         reverb = reverb or {}
         self.desc = ChainDesc(int(has_env), int(has_filter), int(has_reverb), int(stereo),
                               PAN_MODES[pan_mode], int(pan_law is not None), float(pan_law or 0.),
                               float(reverb.get('decay', 1.5)), float(reverb.get('pre_delay', .03)),
-                              float(reverb.get('dry_wet', .7)), int(reverb.get('n_echos', 10)), 0)
+                              float(reverb.get('dry_wet', .7)), int(reverb.get('n_echos', 10)),
+                              int(cutoff_lfo), int(mod_target), 0)
         self.ctx = ctx
         self.n = int(n_voices)
         self.channels = 2 if stereo else 1

@@ -511,10 +511,33 @@ void ko_stereo_mixer(const double *inputs, const double *gains, const double *pa
  * oscillators.py:130-133, envelopes.py:40-45, effects.py:371-385. */
 static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
 {
-    double phase[KO_BUFFER_SIZE], env[KO_BUFFER_SIZE];
+    double phase[KO_BUFFER_SIZE], env[KO_BUFFER_SIZE], mod[KO_BUFFER_SIZE];
+    if (bk->mod_target != KO_MOD_NONE) {
+        /* the modulator: Oscillator.sample / Lfo.sample with shape == BUFFER_SIZE
+         * (oscillators.py:130-133, 178-181): scale * wave(phase) + offset */
+        ko_sample_phase_const(bk->mod_frequency[v], bk->mod_phase[v], phase, &bk->mod_phase[v]);
+        ko_wave(bk->mod_wave[v], phase, KO_BUFFER_SIZE, .5, mod);
+        if (bk->mod_target != KO_MOD_FM)
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                mod[i] = bk->mod_scale[v] * mod[i] + bk->mod_offset[v];
+    }
     if (bk->wave[v] == KO_WAVE_ONE) {
         for (int i = 0; i < KO_BUFFER_SIZE; ++i)
             buf[i] = 1.;
+    } else if (bk->mod_target == KO_MOD_FM) {
+        /* oscillators.py:215-220: wave_func(phase + intensity * modSamples) */
+        ko_sample_phase_const(bk->frequency[v], bk->phase[v], phase, &bk->phase[v]);
+        for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+            phase[i] = phase[i] + bk->mod_scale[v] * mod[i];
+        ko_wave(bk->wave[v], phase, KO_BUFFER_SIZE, bk->duty[v], buf);
+    } else if (bk->mod_target == KO_MOD_FREQUENCY) {
+        ko_sample_phase_array(mod, bk->phase[v], phase, &bk->phase[v]);
+        ko_wave(bk->wave[v], phase, KO_BUFFER_SIZE, bk->duty[v], buf);
+    } else if (bk->mod_target == KO_MOD_DUTY) {
+        /* oscillators.py:256-260 with an array dutyCycle */
+        ko_sample_phase_const(bk->frequency[v], bk->phase[v], phase, &bk->phase[v]);
+        for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+            buf[i] = 2. * (phase[i] < KO_TAU * mod[i] ? 1. : 0.) - 1.;
     } else {
         ko_sample_phase_const(bk->frequency[v], bk->phase[v], phase, &bk->phase[v]);
         ko_wave(bk->wave[v], phase, KO_BUFFER_SIZE, bk->duty[v], buf);
@@ -525,6 +548,16 @@ static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
             buf[i] = bk->amplitude[v] * buf[i] * env[i];
     }
     if (bk->has_filter) {
+        if (bk->cutoff_lfo) {
+            /* Lfo.sample with shape == SCALAR (oscillators.py:175-181), then
+             * Filter.update_frequency -> get_coefficients (effects.py:271-274, 365-373) */
+            const double p = bk->lfo_phase[v];
+            double w;
+            bk->lfo_phase[v] = ko_phasor_step(bk->lfo_frequency[v], p);
+            ko_wave(bk->lfo_wave[v], &p, 1, .5, &w);
+            const double cutoff = bk->lfo_scale[v] * w + bk->lfo_offset[v];
+            bk->coef_index[v] = ko_filter_grid_index(bk->grid, KO_GRID_POINTS, cutoff);
+        }
         const double *c = bk->coef_table + 5 * (size_t)bk->coef_index[v];
         const double b[3] = {c[0], c[1], c[2]};
         const double a[3] = {1., c[3], c[4]};

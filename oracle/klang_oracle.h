@@ -133,7 +133,23 @@ typedef struct {
     double *gain, *pan_l, *pan_r;
     /* state */
     double *phase, *z0, *z1;
+    /* modulation inputs (oscillators.py:143-267, effects.py:365-373); arrays may be
+     * NULL when the feature is off */
+    int cutoff_lfo;            /* 1: Lfo(shape=1) | Filter.frequency, one Lfo per voice */
+    double *lfo_frequency, *lfo_scale, *lfo_offset, *lfo_phase /* state */;
+    int32_t *lfo_wave;
+    const double *grid;        /* [KO_GRID_POINTS] filter frequencies (effects.py:260-265) */
+    int mod_target;            /* KO_MOD_* below: one audio-rate modulator per voice */
+    double *mod_frequency, *mod_scale, *mod_offset, *mod_phase /* state */;
+    int32_t *mod_wave;
 } ko_bank;
+
+enum {
+    KO_MOD_NONE = 0,
+    KO_MOD_FM = 1,         /* FmOscillator: wave(phase + scale * Oscillator(mod_frequency, mod_wave)) */
+    KO_MOD_FREQUENCY = 2,  /* Lfo(shape=256) | Oscillator.frequency (array branch of sample_phase) */
+    KO_MOD_DUTY = 3        /* Lfo(shape=256) | PwmOscillator.dutyCycle */
+};
 
 /* Renders n_blocks blocks.  events must be sorted by (voice, block), stable.
  * mix: [n_blocks][channels][256] float64 (sum in voice order, / n if n > 1).

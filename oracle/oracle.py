@@ -64,7 +64,17 @@ class Bank(C.Structure):
         ('coef_table', _dp),
         ('gain', _dp), ('pan_l', _dp), ('pan_r', _dp),
         ('phase', _dp), ('z0', _dp), ('z1', _dp),
+        ('cutoff_lfo', C.c_int),
+        ('lfo_frequency', _dp), ('lfo_scale', _dp), ('lfo_offset', _dp), ('lfo_phase', _dp),
+        ('lfo_wave', C.POINTER(C.c_int32)),
+        ('grid', _dp),
+        ('mod_target', C.c_int),
+        ('mod_frequency', _dp), ('mod_scale', _dp), ('mod_offset', _dp), ('mod_phase', _dp),
+        ('mod_wave', C.POINTER(C.c_int32)),
     ]
+
+
+MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)
 
 
 _lib = None
@@ -347,6 +357,16 @@ class OracleBank:
         self.z0 = np.zeros(n)
         self.z1 = np.zeros(n)
         self.has_env, self.has_filter, self.stereo = bool(has_env), bool(has_filter), bool(stereo)
+        # modulation inputs (off by default)
+        self.cutoff_lfo = False
+        self.lfo_frequency, self.lfo_scale, self.lfo_offset = np.ones(n), np.ones(n), np.zeros(n)
+        self.lfo_phase = np.zeros(n)
+        self.lfo_wave = np.zeros(n, dtype=np.int32)
+        self.grid = filter_grid()
+        self.mod_target = MOD_NONE
+        self.mod_frequency, self.mod_scale, self.mod_offset = np.ones(n), np.ones(n), np.zeros(n)
+        self.mod_phase = np.zeros(n)
+        self.mod_wave = np.zeros(n, dtype=np.int32)
 
     def set_envelope(self, i, attack, decay, sustain, release, overshoot=1e-3, retrigger=False,
                      loop=False):
@@ -365,12 +385,22 @@ class OracleBank:
     def _struct(self):
         ip = C.POINTER(C.c_int32)
         self.coef_table = _f64(self.coef_table)
+        for name in ('lfo_frequency', 'lfo_scale', 'lfo_offset', 'lfo_phase', 'grid',
+                     'mod_frequency', 'mod_scale', 'mod_offset', 'mod_phase'):
+            setattr(self, name, _f64(getattr(self, name)))
+        self.lfo_wave = np.ascontiguousarray(self.lfo_wave, dtype=np.int32)
+        self.mod_wave = np.ascontiguousarray(self.mod_wave, dtype=np.int32)
         return Bank(self.n, int(self.has_env), int(self.has_filter), int(self.stereo),
                     _p(self.frequency), _p(self.amplitude), _p(self.duty),
                     self.wave.ctypes.data_as(ip), self.env,
                     self.coef_index.ctypes.data_as(ip), _p(self.coef_table),
                     _p(self.gain), _p(self.pan_l), _p(self.pan_r),
-                    _p(self.phase), _p(self.z0), _p(self.z1))
+                    _p(self.phase), _p(self.z0), _p(self.z1),
+                    int(self.cutoff_lfo), _p(self.lfo_frequency), _p(self.lfo_scale),
+                    _p(self.lfo_offset), _p(self.lfo_phase), self.lfo_wave.ctypes.data_as(ip),
+                    _p(self.grid), int(self.mod_target), _p(self.mod_frequency),
+                    _p(self.mod_scale), _p(self.mod_offset), _p(self.mod_phase),
+                    self.mod_wave.ctypes.data_as(ip))
 
     def render(self, n_blocks, events=None, want_voices=False, n_threads=1):
         """events: structured array EVENT_DTYPE (any order; sorted here)."""

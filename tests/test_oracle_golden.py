@@ -384,6 +384,96 @@ def test_config4_mini_reverb_chain(oracle, golden):
                                atol=1e-14)
 
 
+# ---- modulation inputs ------------------------------------------------------
+def _mod_bank(oracle, golden, wave, **kw):
+    table, grid = _ref_table(golden)
+    bank = oracle.OracleBank(1, False, kw.pop('has_filter', False), False)
+    bank.coef_table = table
+    bank.grid = grid
+    bank.wave[:] = wave
+    for k, v in kw.items():
+        setattr(bank, k, v)
+    return bank
+
+
+@pytest.mark.parametrize('wname', WAVES)
+def test_lfo_drives_filter_cutoff(oracle, golden, wname):
+    """Lfo(shape=1) | Filter.frequency (oscillators.py:175-181, effects.py:365-373)."""
+    from klang_amd import patches as P
+    g = golden('modulation')
+    scale, offset = g['lfo_cutoff_scale_offset']
+    bank = _mod_bank(oracle, golden, P.WAVE_SAWTOOTH, has_filter=True, cutoff_lfo=True,
+                     lfo_frequency=np.array([3.7]), lfo_scale=np.array([scale]),
+                     lfo_offset=np.array([offset]), lfo_phase=np.array([.3]),
+                     lfo_wave=np.array([WAVES.index(wname)], dtype=np.int32))
+    bank.frequency[:] = 220.
+    mix, _ = bank.render(40)
+    want = g['lfo_cutoff_%s_out' % wname]
+    if wname == 'sine':   # libm sin of the scalar phase: same grid row unless on an edge
+        np.testing.assert_allclose(mix[:, 0, :], want, rtol=0, atol=1e-12)
+    else:
+        eq(mix[:, 0, :], want)
+    np.testing.assert_allclose(bank.lfo_phase[0], g['lfo_cutoff_%s_final_phase' % wname],
+                               rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('wname', WAVES)
+def test_fm_oscillator(oracle, golden, wname):
+    """FmOscillator (oscillators.py:193-234): wave(phase + intensity * modulator)."""
+    g = golden('modulation')
+    w = WAVES.index(wname)
+    bank = _mod_bank(oracle, golden, w, mod_target=oracle.MOD_FM,
+                     mod_frequency=np.array([110.]), mod_scale=np.array([2.5]),
+                     mod_wave=np.array([w], dtype=np.int32))
+    bank.frequency[:] = 440.
+    mix, _ = bank.render(12)
+    want = g['fm_%s_out' % wname]
+    if wname == 'sine':
+        np.testing.assert_allclose(mix[:, 0, :], want, rtol=0, atol=4e-15)
+    else:
+        eq(mix[:, 0, :], want)
+    eq([bank.phase[0], bank.mod_phase[0]], g['fm_%s_final_phases' % wname])
+
+
+@pytest.mark.parametrize('wname', WAVES)
+def test_audio_rate_lfo_into_frequency(oracle, golden, wname):
+    """Lfo(shape=256) | Oscillator.frequency: the cumsum branch of sample_phase."""
+    from klang_amd import patches as P
+    g = golden('modulation')
+    scale, offset = g['vibrato_scale_offset']
+    bank = _mod_bank(oracle, golden, P.WAVE_SAWTOOTH, mod_target=oracle.MOD_FREQUENCY,
+                     mod_frequency=np.array([5.]), mod_scale=np.array([scale]),
+                     mod_offset=np.array([offset]),
+                     mod_wave=np.array([WAVES.index(wname)], dtype=np.int32))
+    bank.phase[:] = 1.
+    mix, _ = bank.render(12)
+    want = g['vibrato_%s_out' % wname]
+    if wname == 'sine':   # sin ulps enter the running frequency sum
+        np.testing.assert_allclose(mix[:, 0, :], want, rtol=0, atol=1e-11)
+    else:
+        eq(mix[:, 0, :], want)
+        eq([bank.phase[0], bank.mod_phase[0]], g['vibrato_%s_final_phases' % wname])
+
+
+@pytest.mark.parametrize('wname', WAVES)
+def test_audio_rate_lfo_into_duty_cycle(oracle, golden, wname):
+    """Lfo(shape=256) | PwmOscillator.dutyCycle (oscillators.py:256-260)."""
+    from klang_amd import patches as P
+    g = golden('modulation')
+    scale, offset = g['pwm_scale_offset']
+    bank = _mod_bank(oracle, golden, P.WAVE_PWM, mod_target=oracle.MOD_DUTY,
+                     mod_frequency=np.array([2.]), mod_scale=np.array([scale]),
+                     mod_offset=np.array([offset]),
+                     mod_wave=np.array([WAVES.index(wname)], dtype=np.int32))
+    bank.frequency[:] = 220.
+    mix, _ = bank.render(12)
+    got, want = mix[:, 0, :], g['pwm_%s_out' % wname]
+    if wname == 'sine':   # +-1 output: an ulp of the duty moves an edge by at most a sample
+        assert np.mean(got != want) <= 1e-3
+    else:
+        eq(got, want)
+
+
 def test_hello_world_blocks(oracle, golden):
     g = golden('hello_world')
     osc = oracle.OscillatorState(440., 'sine')

@@ -382,6 +382,68 @@ def main():
     cout['config4_mini_mix'] = run_graph(mixer4, p4.n_blocks, hooks, keep=keep4)
     save('chains', **cout)
 
+    # ---- modulation inputs ----------------------------------
+    # oscillators.py:61-64 (array frequency), :143-190 Lfo, :193-234 FmOscillator,
+    # :237-267 PwmOscillator.dutyCycle, effects.py:365-373 Lfo -> Filter.frequency
+    mod = {}
+    wave_names = ('sine', 'square', 'sawtooth', 'triangle')
+    for wname in wave_names:
+        wf = getattr(W, wname)
+        # control-rate Lfo -> Filter.frequency on a saw
+        lfo = OSC.Lfo(frequency=3.7, wave_func=wf, outputRange=(100, 3000), startPhase=.3)
+        osc = OSC.Oscillator(frequency=220., wave_func=W.sawtooth)
+        fil = FX.Filter(frequency=220.)
+        lfo | fil.frequency
+        osc | fil
+        order = determine_execution_order([fil])
+        outs, values = [], []
+        for b in range(40):
+            for blk in order:
+                blk.update()
+            outs.append(np.array(fil.output.value, dtype=float))
+            values.append(float(lfo.output.value))
+        mod['lfo_cutoff_%s_out' % wname] = np.array(outs)
+        mod['lfo_cutoff_%s_values' % wname] = np.array(values)
+        mod['lfo_cutoff_%s_final_phase' % wname] = np.array(lfo.currentPhase)
+        mod['lfo_cutoff_scale_offset'] = np.array([lfo.scale, lfo.offset])
+
+        # FmOscillator: carrier and modulator share the wave function
+        fm = OSC.FmOscillator(frequency=440., intensity=2.5, modFrequency=110., wave_func=wf)
+        outs = []
+        for b in range(12):
+            fm.update()
+            outs.append(np.array(fm.output.value, dtype=float))
+        mod['fm_%s_out' % wname] = np.array(outs)
+        mod['fm_%s_final_phases' % wname] = np.array([fm.currentPhase, fm.modulator.currentPhase])
+
+        # audio-rate Lfo -> Oscillator.frequency (vibrato; cumsum branch of sample_phase)
+        lfo = OSC.Lfo(frequency=5., wave_func=wf, shape=B, outputRange=(430, 450))
+        osc = OSC.Oscillator(frequency=440., wave_func=W.sawtooth, startPhase=1.)
+        lfo | osc.frequency
+        order = determine_execution_order([osc])
+        outs = []
+        for b in range(12):
+            for blk in order:
+                blk.update()
+            outs.append(np.array(osc.output.value, dtype=float))
+        mod['vibrato_%s_out' % wname] = np.array(outs)
+        mod['vibrato_%s_final_phases' % wname] = np.array([osc.currentPhase, lfo.currentPhase])
+        mod['vibrato_scale_offset'] = np.array([lfo.scale, lfo.offset])
+
+        # audio-rate Lfo -> PwmOscillator.dutyCycle
+        lfo = OSC.Lfo(frequency=2., wave_func=wf, shape=B, outputRange=(.1, .9))
+        pwm = OSC.PwmOscillator(frequency=220.)
+        lfo | pwm.dutyCycle
+        order = determine_execution_order([pwm])
+        outs = []
+        for b in range(12):
+            for blk in order:
+                blk.update()
+            outs.append(np.array(pwm.output.value, dtype=float))
+        mod['pwm_%s_out' % wname] = np.array(outs)
+        mod['pwm_scale_offset'] = np.array([lfo.scale, lfo.offset])
+    save('modulation', **mod)
+
     # ---- hello_world (config 1): Oscillator(440) | Dac, pre-normalisation ---
     osc = OSC.Oscillator(frequency=440.)
     blocks = []
