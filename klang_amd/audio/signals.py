@@ -164,6 +164,32 @@ class Lfo(Phasor):
                     outputRange=self.outputRange)
 
 
+class FmOscillator(Oscillator):
+    """Frequency modulation oscillator: wave(phase + intensity * modulator), the
+    modulator being an inner Oscillator of the same wave function
+    (oscillators.py:193-234)."""
+
+    def __init__(self, frequency=440., intensity=1., modFrequency=10., wave_func=sine,
+                 startPhase=0.):
+        super().__init__(frequency, wave_func, startPhase)
+        self.intensity = intensity
+        self.modulator = Oscillator(modFrequency, wave_func=wave_func)
+
+    def sample(self):
+        freq = compute_rate(self.frequency.value)
+        phase, self.currentPhase = sample_phase(freq, self.currentPhase)
+        return self.wave_func(phase + self.intensity * self.modulator.output.value)
+
+    def update(self):
+        self.modulator.update()
+        self.output.set_value(self.sample())
+
+    def _ctor_kwargs(self):
+        return dict(frequency=self.frequency.value, intensity=self.intensity,
+                    modFrequency=self.modulator.frequency.value, wave_func=self.wave_func,
+                    startPhase=self.currentPhase)
+
+
 class PwmOscillator(Phasor):
     """Pulse wave with a duty-cycle input (oscillators.py:237-267)."""
 

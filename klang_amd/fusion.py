@@ -5,8 +5,12 @@ The execution order stays the one derived from the DAG (klang_amd/schedule.py,
 klang/execution.py:37-58 in the reference).  In that order every ``Mixer`` /
 ``StereoMixer`` whose inputs are all *voice chains* of one shape
 
-    Voice(Oscillator|PwmOscillator, ADSR|AR|D|R)  or a bare oscillator
+    Voice(Oscillator|PwmOscillator|FmOscillator, ADSR|AR|D|R)  or a bare oscillator
         [ | Filter ]  [ | Reverb ]   ->  mixer input
+
+with, optionally, one modulation source per voice:
+``Lfo(shape=1) | filter.frequency``, ``Lfo(shape=256) | oscillator.frequency``,
+``Lfo(shape=256) | pwm.dutyCycle`` or an ``FmOscillator`` (its inner modulator)
 
 is replaced, together with the chain blocks, by one ``GpuVoiceBank`` block that
 owns a device-resident ``klang_amd.native.Bank`` (one voice per mixer input).
@@ -26,7 +30,8 @@ from klang_amd import native
 from klang_amd.audio.envelopes import EnvelopeBase
 from klang_amd.audio.filtering import BackwardCombFilter, Filter, Reverb
 from klang_amd.audio.mixers import Mixer, StereoMixer
-from klang_amd.audio.signals import Lfo, Oscillator, Phasor, PwmOscillator, WAVE_IDS
+from klang_amd.audio.signals import (BUFFER_SIZE, SCALAR, FmOscillator, Lfo, Oscillator, Phasor,
+                                      PwmOscillator, WAVE_IDS)
 from klang_amd.audio.voices import Voice
 from klang_amd.block import Block
 from klang_amd.composite import Composite
@@ -48,7 +53,27 @@ class Chain:
         self.end = end
         self.blocks = []
         self.voice = self.oscillator = self.envelope = self.filter = self.reverb = None
+        self.cutoff_lfo = None          # Lfo(shape=1) | filter.frequency
+        self.mod_target = native.MOD_NONE
+        self.modulator = None           # Lfo(shape=256) or FmOscillator.modulator
         self._walk(end)
+
+    @staticmethod
+    def _private_lfo(inp, shape, what):
+        """The Lfo behind `inp`, if it is one the device can evaluate for this
+        voice alone: right shape, device wave, constant frequency, one consumer."""
+        src = inp.incomingConnection
+        lfo = src.owner if src is not None else None
+        if type(lfo) is not Lfo or lfo.shape != shape:
+            raise NotFusable('%s: only an Lfo(shape=%d) is fused as modulation source'
+                             % (what, shape))
+        if lfo.wave_func not in WAVE_IDS:
+            raise NotFusable('%s: Lfo wave function %r has no device twin' % (what, lfo.wave_func))
+        if lfo.frequency.connected or np.ndim(lfo.frequency.value) != 0:
+            raise NotFusable('%s: the Lfo\'s own frequency is modulated' % what)
+        if len(src.outgoingConnections) != 1:
+            raise NotFusable('%s: the Lfo feeds more than one input' % what)
+        return lfo
 
     def _walk(self, block):
         stage = block
@@ -58,7 +83,7 @@ class Chain:
             self.reverb, stage = stage, self._upstream(stage)
         if isinstance(stage, Filter):
             if stage.frequency.connected:
-                raise NotFusable('%s: modulated cutoff inputs are not fused yet' % stage)
+                self.cutoff_lfo = self._private_lfo(stage.frequency, SCALAR, '%s.frequency' % stage)
             self.filter, stage = stage, self._upstream(stage)
         if isinstance(stage, Voice):
             self.voice = stage
@@ -71,15 +96,35 @@ class Chain:
         else:
             self.oscillator = stage
         osc = self.oscillator
-        if type(osc) not in (Oscillator, PwmOscillator):
+        if type(osc) not in (Oscillator, PwmOscillator, FmOscillator):
             raise NotFusable('%s is not an oscillator the device evaluates' % osc)
-        if type(osc) is Oscillator and osc.wave_func not in WAVE_IDS:
+        if type(osc) is not PwmOscillator and osc.wave_func not in WAVE_IDS:
             raise NotFusable('%s: wave function %r has no device twin' % (osc, osc.wave_func))
-        if any(i.connected for i in osc.inputs):
-            raise NotFusable('%s: modulated oscillator inputs are not fused yet' % osc)
-        if np.ndim(osc.frequency.value) != 0:
-            raise NotFusable('%s: array-rate frequency is not fused yet' % osc)
-        self.blocks = [b for b in (self.voice or self.oscillator, self.filter, self.reverb) if b]
+        if type(osc) is FmOscillator:
+            mod = osc.modulator
+            if (type(mod) is not Oscillator or mod.wave_func not in WAVE_IDS
+                    or mod.frequency.connected or np.ndim(mod.frequency.value) != 0
+                    or any(o.connected for o in mod.outputs)):
+                raise NotFusable('%s: its modulator is not a plain inner Oscillator' % osc)
+            self.mod_target, self.modulator = native.MOD_FM, mod
+        if osc.frequency.connected:
+            if self.modulator is not None:
+                raise NotFusable('%s: one audio-rate modulation source per voice' % osc)
+            self.modulator = self._private_lfo(osc.frequency, BUFFER_SIZE, '%s.frequency' % osc)
+            self.mod_target = native.MOD_FREQUENCY
+        elif np.ndim(osc.frequency.value) != 0:
+            raise NotFusable('%s: a constant frequency array is not fused' % osc)
+        if type(osc) is PwmOscillator and osc.dutyCycle.connected:
+            if self.modulator is not None:
+                raise NotFusable('%s: one audio-rate modulation source per voice' % osc)
+            self.modulator = self._private_lfo(osc.dutyCycle, BUFFER_SIZE, '%s.dutyCycle' % osc)
+            self.mod_target = native.MOD_DUTY
+        elif type(osc) is PwmOscillator and np.ndim(osc.dutyCycle.value) != 0:
+            raise NotFusable('%s: a constant duty-cycle array is not fused' % osc)
+        self.blocks = [b for b in (self.voice or self.oscillator, self.filter, self.reverb,
+                                   self.cutoff_lfo,
+                                   self.modulator if self.mod_target != native.MOD_FM else None)
+                       if b]
 
     @staticmethod
     def _upstream(block):
@@ -94,7 +139,8 @@ class Chain:
     def shape(self):
         rv = self.reverb
         return (self.voice is not None, self.filter is not None,
-                (rv.decay, rv.preDelay, rv.dryWet, rv.nEchos) if rv else None)
+                (rv.decay, rv.preDelay, rv.dryWet, rv.nEchos) if rv else None,
+                self.cutoff_lfo is not None, self.mod_target)
 
     def wave_id(self):
         if isinstance(self.oscillator, PwmOscillator):
@@ -110,7 +156,8 @@ class GpuVoiceBank(Block):
         super().__init__()
         self.chains, self.sink = chains, sink
         self.ctx = ctx or native.default_context()
-        has_env, has_filter, reverb = chains[0].shape
+        has_env, has_filter, reverb, cutoff_lfo, mod_target = chains[0].shape
+        self.cutoff_lfo, self.mod_target = cutoff_lfo, mod_target
         self.stereo = isinstance(sink, StereoMixer)
         self.is_mixer = isinstance(sink, Mixer)
         kw = {}
@@ -120,7 +167,7 @@ class GpuVoiceBank(Block):
             self.ctx, len(chains), has_env=has_env, has_filter=has_filter,
             has_reverb=reverb is not None, stereo=self.stereo,
             reverb=dict(zip(('decay', 'pre_delay', 'dry_wet', 'n_echos'), reverb)) if reverb else None,
-            **kw)
+            cutoff_lfo=cutoff_lfo, mod_target=mod_target, **kw)
         self.lookahead = 1      # blocks rendered per device call (set by run_klang)
         self.remaining = None   # buffers still to be delivered, when the caller knows (offline
                                 # bounce): rendering ahead never runs past the end of the piece
@@ -132,10 +179,28 @@ class GpuVoiceBank(Block):
         F, bank, ch = native, self.bank, self.chains
         oscs = [c.oscillator for c in ch]
         bank.set(F.F_WAVE, [c.wave_id() for c in ch])
-        bank.set(F.F_FREQUENCY, [float(compute_rate(o.frequency.value)) for o in oscs])
-        bank.set(F.F_DUTY, [float(o.dutyCycle.value) if isinstance(o, PwmOscillator) else .5
+        if self.mod_target != F.MOD_FREQUENCY:
+            bank.set(F.F_FREQUENCY, [float(compute_rate(o.frequency.value)) for o in oscs])
+        bank.set(F.F_DUTY, [float(o.dutyCycle.value)
+                            if isinstance(o, PwmOscillator) and self.mod_target != F.MOD_DUTY else .5
                             for o in oscs])
         bank.set_state(F.F_PHASE, [float(o.currentPhase) for o in oscs])
+        if self.mod_target != F.MOD_NONE:
+            mods = [c.modulator for c in ch]
+            fm = self.mod_target == F.MOD_FM
+            bank.set(F.F_MOD_FREQUENCY, [float(compute_rate(m.frequency.value)) for m in mods])
+            bank.set(F.F_MOD_WAVE, [WAVE_IDS[m.wave_func] for m in mods])
+            bank.set(F.F_MOD_SCALE, [float(c.oscillator.intensity if fm else c.modulator.scale)
+                                     for c in ch])
+            bank.set(F.F_MOD_OFFSET, [0. if fm else float(m.offset) for m in mods])
+            bank.set_state(F.F_MOD_PHASE, [float(m.currentPhase) for m in mods])
+        if self.cutoff_lfo:
+            lfos = [c.cutoff_lfo for c in ch]
+            bank.set(F.F_LFO_FREQUENCY, [float(compute_rate(l.frequency.value)) for l in lfos])
+            bank.set(F.F_LFO_WAVE, [WAVE_IDS[l.wave_func] for l in lfos])
+            bank.set(F.F_LFO_SCALE, [float(l.scale) for l in lfos])
+            bank.set(F.F_LFO_OFFSET, [float(l.offset) for l in lfos])
+            bank.set_state(F.F_LFO_PHASE, [float(l.currentPhase) for l in lfos])
         if ch[0].voice is not None:
             envs = [c.envelope for c in ch]
             for field, name in ((F.F_ATTACK, 'attack'), (F.F_DECAY, 'decay'),
@@ -147,7 +212,7 @@ class GpuVoiceBank(Block):
             bank.set_state(F.F_ENV_VALUE, [e.value for e in envs])
             bank.set_state(F.F_ENV_STAGE, [e.stage for e in envs])
             bank.set_state(F.F_ENV_ENABLED, [float(e.enabled) for e in envs])
-        if ch[0].filter is not None:
+        if ch[0].filter is not None and not self.cutoff_lfo:
             bank.set(F.F_CUTOFF, [float(c.filter.frequency.value) for c in ch])
             self._cutoffs = [c.filter.frequency.value for c in ch]
         if self.is_mixer:
@@ -175,7 +240,8 @@ class GpuVoiceBank(Block):
                 for note in c.envelope.input.receive():        # envelopes.py:40-42
                     bank.event(i, 0, F.EV_NOTE_ON if note.on else F.EV_NOTE_OFF,
                                c.voice.amplitude, float(compute_rate(c.oscillator.frequency.value)))
-            if c.filter is not None and c.filter.frequency.value != self._cutoffs[i]:
+            if (c.filter is not None and not self.cutoff_lfo
+                    and c.filter.frequency.value != self._cutoffs[i]):
                 self._cutoffs[i] = c.filter.frequency.value
                 bank.event(i, 0, F.EV_SET_CUTOFF, 0., float(self._cutoffs[i]))
         if self.is_mixer:
@@ -214,6 +280,12 @@ class GpuVoiceBank(Block):
         phase = bank.get_state(F.F_PHASE)
         for i, c in enumerate(self.chains):
             c.oscillator.currentPhase = float(phase[i])
+        if self.mod_target != F.MOD_NONE:
+            for c, p in zip(self.chains, bank.get_state(F.F_MOD_PHASE)):
+                c.modulator.currentPhase = float(p)
+        if self.cutoff_lfo:
+            for c, p in zip(self.chains, bank.get_state(F.F_LFO_PHASE)):
+                c.cutoff_lfo.currentPhase = float(p)
         if self.chains[0].voice is not None:
             value, stage = bank.get_state(F.F_ENV_VALUE), bank.get_state(F.F_ENV_STAGE)
             enabled = bank.get_state(F.F_ENV_ENABLED)

@@ -118,9 +118,85 @@ def test_reverb_chain_and_parameter_edits(hip, oracle):
 
 def test_strict_backend_refuses_unfusable_hot_path_blocks(hip):
     from klang_amd.audio import Lfo
-    lfo = Lfo(frequency=2., outputRange=(200., 2000.))
-    osc, fil = Oscillator(wave_func=sawtooth), Filter()
-    lfo | fil.frequency
+    lfo = Lfo(frequency=2., outputRange=(200., 2000.))       # control-rate Lfo ...
+    osc = Oscillator(wave_func=sawtooth)
+    lfo | osc.frequency                                      # ... into an audio-rate input
     with pytest.raises(KlangError) as e:
-        run_klang(osc | fil | Dac(), offline=True, duration=.1)
-    assert "backend='hip'" in str(e.value) and 'modulated cutoff' in str(e.value)
+        run_klang(osc | Dac(), offline=True, duration=.1)
+    assert "backend='hip'" in str(e.value) and 'shape=256' in str(e.value)
+
+
+def _modulated_patches():
+    """Builders of small patches with one modulation source per voice."""
+    from klang_amd.audio import FmOscillator, Lfo, PwmOscillator, triangle, square
+
+    def arp_like():   # examples/arpeggiator_demo.py:35-49: Lfo | fil.frequency, voice | fil
+        mixer = Mixer()
+        for k in range(5):
+            lfo = Lfo(frequency=2. + k, wave_func=triangle, outputRange=(100, 3000), startPhase=.2 * k)
+            fil = Filter(frequency=220.)
+            lfo | fil.frequency
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+            voice | fil
+            mixer += fil
+            voice.input.push(Note(0, .5 + .1 * k, frequency=110. * (k + 1)))
+        return mixer | Dac()
+
+    def fm():
+        mixer = Mixer()
+        for k in range(4):
+            mixer += FmOscillator(220. * (k + 1), intensity=.5 + k, modFrequency=55. + 10 * k,
+                                  wave_func=(sine, sawtooth, triangle, square)[k])
+        return mixer | Dac()
+
+    def vibrato():
+        mixer = Mixer()
+        for k in range(4):
+            lfo = Lfo(4. + k, wave_func=(sine, triangle)[k % 2], shape=B, outputRange=(430 + k, 450 + k))
+            osc = Oscillator(440., wave_func=(sawtooth, sine)[k // 2], startPhase=.1 * k)
+            lfo | osc.frequency
+            mixer += osc
+        return mixer | Dac()
+
+    def pwm():
+        mixer = Mixer()
+        for k in range(3):
+            lfo = Lfo(1. + k, wave_func=triangle, shape=B, outputRange=(.1, .9))
+            osc = PwmOscillator(110. * (k + 1))
+            lfo | osc.dutyCycle
+            mixer += osc
+        return mixer | Dac()
+
+    return dict(arp_like=arp_like, fm=fm, vibrato=vibrato, pwm=pwm)
+
+
+@pytest.mark.parametrize('name', ['arp_like', 'fm', 'vibrato', 'pwm'])
+def test_modulated_patches_match_the_host_evaluation(hip, name):
+    """backend='hip' fuses the Lfo / modulator into the bank (no host DSP block is left)
+    and reproduces the explicit NumPy evaluation of the same patch."""
+    build = _modulated_patches()[name]
+    order, banks = fusion.compile_order(determine_execution_order([build()]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac']
+    for bank in banks:
+        bank.close()
+    dur = 20 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0.))
+    want = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert got.shape == want.shape and np.abs(want).max() > .05
+    if name == 'pwm':   # +-1 edges: float32 vs float64 duty may move one by a sample
+        assert np.mean(np.abs(got - want) > 1e-5) <= 2e-3
+    else:
+        assert np.abs(got - want).max() <= 1e-5
+
+
+def test_modulator_state_is_copied_back_to_the_host_blocks(hip):
+    from klang_amd.audio import Lfo, triangle
+    lfo = Lfo(frequency=3., wave_func=triangle, outputRange=(100, 3000))
+    fil = Filter()
+    lfo | fil.frequency
+    osc = Oscillator(220., wave_func=sawtooth)
+    run_klang(osc | fil | Dac(), offline=True, duration=10 * B / 44100. + 1e-9)
+    twin = Lfo(frequency=3., wave_func=triangle, outputRange=(100, 3000))
+    for _ in range(10):
+        twin.update()
+    assert lfo.currentPhase == twin.currentPhase

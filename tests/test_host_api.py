@@ -211,3 +211,61 @@ def test_dac_channel_collection():
     dac.inputs[0].set_value(np.ones((2, 256)))
     out = dac.collect_samples()
     assert out.shape == (256, 2) and out.dtype == np.float32
+
+
+# ---- graph compiler: modulation sources -------------------------------------------
+def test_fuser_recognises_modulation_sources():
+    from klang_amd import fusion, native
+    from klang_amd.audio import (ADSR, Filter, FmOscillator, Lfo, Mixer, Oscillator, PwmOscillator,
+                                 Voice, sawtooth, triangle)
+    from klang_amd.schedule import determine_execution_order
+
+    def chains_of(top):
+        groups, errors = fusion.find_fusable(determine_execution_order([top]))
+        return groups, errors
+
+    # arpeggiator_demo.py:35-49 in small: Lfo | fil.frequency, voice | fil
+    lfo = Lfo(frequency=.1, wave_func=triangle, outputRange=(100, 3000))
+    fil = Filter(frequency=220.)
+    lfo | fil.frequency
+    voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.1, .2, .3, .4))
+    mixer = Mixer()
+    mixer += (voice | fil)
+    groups, errors = chains_of(mixer)
+    assert not errors and len(groups) == 1
+    chain = groups[0][1][0]
+    assert chain.cutoff_lfo is lfo and chain.mod_target == native.MOD_NONE
+    assert lfo in chain.blocks
+
+    fm = FmOscillator(440., intensity=2., modFrequency=55.)
+    groups, errors = chains_of(fm)
+    assert not errors and groups[0][1][0].mod_target == native.MOD_FM
+    assert groups[0][1][0].modulator is fm.modulator
+
+    vib = Lfo(5., shape=256, outputRange=(430, 450))
+    osc = Oscillator(440., wave_func=sawtooth)
+    vib | osc.frequency
+    groups, errors = chains_of(osc)
+    assert not errors and groups[0][1][0].mod_target == native.MOD_FREQUENCY
+
+    duty = Lfo(2., shape=256, outputRange=(.1, .9))
+    pwm = PwmOscillator(220.)
+    duty | pwm.dutyCycle
+    groups, errors = chains_of(pwm)
+    assert not errors and groups[0][1][0].mod_target == native.MOD_DUTY
+
+    # refused: control-rate Lfo into an audio-rate input, shared Lfo, modulated Lfo
+    slow = Lfo(1.)
+    osc2 = Oscillator(440.)
+    slow | osc2.frequency
+    groups, errors = chains_of(osc2)
+    assert not groups and 'shape=256' in errors[0]
+    shared = Lfo(1., outputRange=(100, 1000))
+    f1, f2 = Filter(), Filter()
+    shared | f1.frequency
+    shared | f2.frequency
+    m2 = Mixer()
+    m2 += (Oscillator(220.) | f1)
+    m2 += (Oscillator(330.) | f2)
+    groups, errors = chains_of(m2)
+    assert any('more than one input' in e for e in errors)

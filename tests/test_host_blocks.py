@@ -213,7 +213,7 @@ def test_find_fusable_matches_voice_filter_mixer():
     assert not errors and len(groups) == 1
     sink, chains = groups[0]
     assert sink is mixer and len(chains) == 6
-    assert chains[0].shape == (True, True, None)
+    assert chains[0].shape == (True, True, None, False, 0)
     assert [c.voice for c in chains] == voices and chains[0].wave_id() == 2
 
 
@@ -227,16 +227,16 @@ def test_find_fusable_single_chain_and_reverb_shape():
     dac = voice | rv | Dac()
     groups, errors = fusion.find_fusable(determine_execution_order([dac]))
     assert not errors and groups[0][0] is rv
-    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10))
+    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10), False, 0)
 
 
 def test_find_fusable_reports_what_it_cannot_fuse():
-    lfo = Lfo(frequency=2., outputRange=(200., 2000.))
+    lfo = Lfo(frequency=2., shape=256, outputRange=(200., 2000.))
     osc, fil = Oscillator(wave_func=sawtooth), Filter()
-    lfo | fil.frequency            # modulated cutoff: a "next" row, not fused yet
+    lfo | fil.frequency            # an audio-rate Lfo cannot drive the per-buffer cutoff
     dac = osc | fil | Dac()
     groups, errors = fusion.find_fusable(determine_execution_order([dac]))
-    assert any('modulated cutoff' in e for e in errors)
+    assert any('shape=1' in e for e in errors)
     shared = Oscillator()
     m = Mixer()
     m += shared
