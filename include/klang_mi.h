@@ -123,12 +123,35 @@ typedef enum {
                                 (oscillators.py:256-260) */
 } klmi_mod_target;
 
+/* Effect stages of a voice chain, in patch order between the voice and the
+ * reverb / mixer (klang/audio/effects.py).  Parameters are set per voice with
+ * klmi_bank_set_params(bank, KLMI_F_FX(stage, k), ...), k as listed. */
+typedef enum {
+    KLMI_FX_NONE = 0,
+    KLMI_FX_FILTER = 1,     /* the chain's Filter (desc.has_filter) sits here; KLMI_F_CUTOFF */
+    KLMI_FX_GAIN = 2,       /* Gain (effects.py:58-70): k0 gain */
+    KLMI_FX_TRANSFORM = 3,  /* Transformer (effects.py:522-561): k0 scale, k1 offset */
+    KLMI_FX_TANH = 4,       /* TanhDistortion (effects.py:469-487): k0 drive */
+    KLMI_FX_OCTAVE = 5,     /* OctaveDistortion (effects.py:452-466) */
+    KLMI_FX_TREMOLO = 6,    /* Tremolo (effects.py:73-133): k0 rate (Hz), k1 depth,
+                               k2 smoothness, k3 dutyCycle; state k0 lfo phase, k1 zi */
+    KLMI_FX_DELAY = 7       /* Delay (effects.py:136-174): k0 time (s, <= 2; at least one
+                               buffer: 256 samples), k1 feedback, k2 drywet; state k0 ring
+                               position.  Setting k0 clears the delay line. */
+} klmi_fx_kind;
+#define KLMI_MAX_FX 8
+#define KLMI_F_FX(stage, k) (64 + 4 * (stage) + (k))        /* parameter k = 0..3 of a stage */
+#define KLMI_F_FX_STATE(stage, k) (128 + 2 * (stage) + (k)) /* state k = 0..1 of a stage */
+
 /* What one bank evaluates per voice, in the reference's terms:
  *   osc = Oscillator(wave_func)                     oscillators.py:111-140
  *         (mod_target: FmOscillator / modulated frequency / modulated duty cycle)
  *   x   = has_env ? (amplitude*osc)*ADSR/AR/D/R     voices.py:66-74, envelopes.py:18-114
  *   x   = has_filter ? Filter(x)                    effects.py:342-385
  *         (cutoff_lfo: Filter.frequency driven per buffer by the voice's own Lfo)
+ *   x   = fx[0](x), fx[1](x), ...                   when n_fx > 0: the stages in patch
+ *         order, the Filter among them as KLMI_FX_FILTER (at most one Filter, one
+ *         Tremolo and one Delay per chain); n_fx == 0 is the plain [Filter] chain
  *   x   = has_reverb ? Reverb(x)                    effects.py:564-615
  *   bus = stereo ? StereoMixer : Mixer over voices  mixer.py:15-104
  */
@@ -146,7 +169,8 @@ typedef struct {
     int32_t reverb_n_echos;   /* nEchos > 0 */
     int32_t cutoff_lfo;       /* 1: Lfo(shape=1) | Filter.frequency per voice (needs has_filter) */
     int32_t mod_target;       /* klmi_mod_target */
-    int32_t reserved;
+    int32_t n_fx;             /* number of effect stages, 0..KLMI_MAX_FX */
+    uint8_t fx[KLMI_MAX_FX];  /* klmi_fx_kind per stage */
 } klmi_chain_desc;
 
 /* Block-boundary events, the batched form of Voice.process_incoming_notes

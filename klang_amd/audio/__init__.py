@@ -5,6 +5,8 @@ from klang_amd.audio.signals import (FmOscillator, Lfo, Oscillator, Phasor, PwmO
 from klang_amd.audio.envelopes import ADSR, AR, D, R, Envelope
 from klang_amd.audio.filtering import (BackwardCombFilter, EchoFilter, Filter,
                                        ForwardCombFilter, Reverb)
+from klang_amd.audio.effects import (Delay, Gain, OctaveDistortion, TanhDistortion, Transformer,
+                                     Tremolo)
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.voices import Voice
 from klang_amd.audio.engine import Adc, Dac, run_audio_engine, write_wave
@@ -12,4 +14,5 @@ from klang_amd.audio.engine import Adc, Dac, run_audio_engine, write_wave
 __all__ = ['FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscillator', 'WAVE_FUNCTIONS', 'sample_phase',
            'sawtooth', 'sine', 'square', 'triangle', 'ADSR', 'AR', 'D', 'R', 'Envelope',
            'BackwardCombFilter', 'EchoFilter', 'Filter', 'ForwardCombFilter', 'Reverb', 'Mixer',
-           'StereoMixer', 'Voice', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']
+           'StereoMixer', 'Voice', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
+           'Transformer', 'Tremolo', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']

@@ -1,0 +1,191 @@
+"""Element-wise and delay effects (host side): ``Gain``, ``Transformer``,
+``TanhDistortion``, ``OctaveDistortion``, ``Tremolo``, ``Delay``.
+
+Mirrors klang/audio/effects.py:33-174, 452-561 and klang/ring_buffer.py:10-113.
+The ``update()`` methods are the ``backend='host'`` evaluation; inside a fused
+voice chain the same stages run on the device (mod_kernels.h).
+"""
+import functools
+import math
+
+import numpy as np
+
+from klang_amd import native
+from klang_amd.audio.filtering import blend
+from klang_amd.audio.signals import PwmOscillator
+from klang_amd.block import Block
+from klang_amd.composite import Composite
+from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
+from klang_amd.constants import MONO
+from klang_amd.tempo import compute_duration
+from klang_amd.wiring import Input, Relay
+
+__all__ = ['Gain', 'Transformer', 'TanhDistortion', 'OctaveDistortion', 'Tremolo', 'Delay',
+           'DelayLine', 'low_pass_coefficients']
+
+
+@functools.lru_cache()
+def low_pass_coefficients(frequency):
+    """Single-pole low-pass (b, a) (effects.py:33-55), from the library's helper."""
+    return native.low_pass_coefficients(float(frequency))
+
+
+class Gain(Block):
+    """gain * samples, the gain being a value input (effects.py:58-70)."""
+
+    def __init__(self, gain=1.):
+        super().__init__(nInputs=2, nOutputs=1)
+        _, self.gain = self.inputs
+        self.gain.set_value(gain)
+
+    def update(self):
+        self.output.set_value(self.gain.value * self.input.value)
+
+
+class Transformer(Block):
+    """scale * samples + offset (effects.py:522-561)."""
+
+    def __init__(self, scale, offset):
+        super().__init__(nInputs=1, nOutputs=1)
+        self.scale, self.offset = scale, offset
+
+    @classmethod
+    def from_limits(cls, lower, upper):
+        """Input range [0, 1] -> [lower, upper]."""
+        assert lower < upper
+        return cls(scale=upper - lower, offset=lower)
+
+    @classmethod
+    def from_limits_2(cls, lower, upper):
+        """Input range [-1, 1] -> [lower, upper]."""
+        assert lower < upper
+        width = upper - lower
+        return cls(scale=.5 * width, offset=lower + .5 * width)
+
+    @classmethod
+    def from_ranges(cls, xRange=(0., 1.), yRange=(0., 1.)):
+        from klang_amd.audio.signals import linear_mapping
+        return cls(*linear_mapping(xRange, yRange))
+
+    def update(self):
+        self.output.set_value(self.scale * self.input.value + self.offset)
+
+
+class TanhDistortion(Block):
+    """tanh(drive * samples) (effects.py:469-487)."""
+
+    def __init__(self, drive=1.):
+        super().__init__(nInputs=1, nOutputs=1)
+        self.drive = drive
+
+    def update(self):
+        self.output.set_value(np.tanh(self.drive * self.input.get_value()))
+
+
+class OctaveDistortion(Block):
+    """2 * samples**2 - 1 (effects.py:452-466)."""
+
+    def __init__(self):
+        super().__init__(nInputs=1, nOutputs=1)
+
+    def update(self):
+        samples = self.input.get_value()
+        self.output.set_value(2. * samples ** 2 - 1.)
+
+
+class Tremolo(Composite):
+    """Amplitude modulation by a low-passed pulse Lfo (effects.py:73-133):
+    env = (1 - depth) + depth * (.5 + .5 * lowpass(pwm)), out = env * x."""
+
+    def __init__(self, rate=3., depth=.8, smoothness=1., dutyCycle=.5):
+        super().__init__(nOutputs=1)
+        self.inputs = [Input(owner=self), Relay(owner=self), Input(owner=self),
+                       Input(owner=self), Relay(owner=self)]
+        _, self.rate, self.depth, self.smoothness, self.dutyCycle = self.inputs
+        self.rate.set_value(rate)
+        self.depth.set_value(depth)
+        self.smoothness.set_value(smoothness)
+        self.dutyCycle.set_value(dutyCycle)
+        self.lfo = PwmOscillator(rate)
+        self.rate.connect(self.lfo.frequency)
+        self.dutyCycle.connect(self.lfo.dutyCycle)
+        self.zi = np.zeros(1)
+
+    @staticmethod
+    def smoothing_coefficients(smoothness, dutyCycle):
+        decay = max(1e-6, smoothness * min(dutyCycle, 1. - dutyCycle))
+        return low_pass_coefficients(1. / decay)
+
+    def update(self):
+        depth = self.depth.value
+        (b0,), (_, a1) = self.smoothing_coefficients(self.smoothness.value, self.dutyCycle.value)
+        self.lfo.update()
+        pwm = self.lfo.output.value
+        # scipy.signal.lfilter([b0], [1, a1], pwm, zi): direct form II transposed, order 1
+        smooth = np.empty(BUFFER_SIZE)
+        z = float(self.zi[0])
+        for i in range(BUFFER_SIZE):
+            y = z + b0 * pwm[i]
+            z = 0. * pwm[i] - a1 * y
+            smooth[i] = y
+        self.zi = np.array([z])
+        env = (1. - depth) + depth * (.5 + .5 * smooth)
+        self.output.set_value(env * self.input.value)
+
+
+class DelayLine:
+    """Circular sample store with klang.ring_buffer.RingBuffer's contract
+    (ring_buffer.py:10-113): `length` live samples inside a store that is
+    over-allocated by one buffer, whose first `bufferSize` samples are mirrored
+    behind the end so that a window starting at any position is contiguous.
+    ``peek()`` returns a VIEW (no copy), exactly like the reference."""
+
+    def __init__(self, length, capacity=None, bufferSize=BUFFER_SIZE):
+        self.length = int(length)
+        self.capacity = self.length if capacity is None else int(capacity)
+        self.bufferSize = bufferSize
+        self.data = np.zeros(self.capacity + bufferSize)
+        self.pos = 0
+
+    def peek(self, nValues=None):
+        count = self.bufferSize if nValues is None else nValues
+        return self.data[self.pos:self.pos + count]
+
+    def extend(self, values):
+        count = len(values)
+        if count > self.bufferSize:
+            raise ValueError('To many samples!')
+        first, last = self.pos, self.pos + count
+        self.data[first:last] = values
+        if first < self.bufferSize:                      # keep the mirror behind the end
+            lo = first + self.length
+            hi = min(self.length + self.bufferSize, last + self.length)
+            self.data[lo:hi] = values[:hi - lo]
+        if last > self.length:                           # wrapped: the head gets the rest
+            lo = max(0, first - self.length)
+            hi = last - self.length
+            self.data[lo:hi] = values[-(hi - lo):]
+        self.pos = (self.pos + count) % self.length
+
+
+class Delay(Block):
+    """Mono feedback delay (effects.py:136-174).  The dry/wet blend reads the
+    ring window AFTER the new samples were written into it (the window is a
+    view), so the wet part is new + feedback * delayed, as in the reference."""
+    MAX_TIME = 2.
+
+    def __init__(self, time=1., feedback=.1, drywet=.5):
+        if time > self.MAX_TIME:
+            raise ValueError('Delay time %.3f sec to long (max %.3f)!' % (time, self.MAX_TIME))
+        super().__init__(nInputs=1, nOutputs=1)
+        self.feedback, self.drywet = feedback, drywet
+        self.time = compute_duration(time)
+        self.ring = DelayLine(int(self.time * SAMPLING_RATE), int(self.MAX_TIME * SAMPLING_RATE))
+
+    def update(self):
+        new = self.input.get_value()
+        if np.ndim(new) != MONO:
+            new = new.sum(axis=0) / new.shape[0]
+        old = self.ring.peek()
+        self.ring.extend(new + self.feedback * old)
+        self.output.set_value(blend(new, old, self.drywet))

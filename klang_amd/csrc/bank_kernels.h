@@ -53,7 +53,20 @@ struct BankView {
     const double *mod_par;     // [3][n]: frequency, scale (FM: intensity), offset
     const int32_t *mod_wave;
     double *mod_phase;         // state
+    // effect stages, in patch order; n_fx == 0: the plain [Filter] chain
+    int n_fx;
+    unsigned char fx_kind[8];  // FxKind
+    const double *fx_par;      // [8][kFxSlots][n] per-stage device parameters
+    double *fx_state;          // [8][2][n]: tremolo lfo phase, zi; delay position
+    double *fx_ring;           // the delay stage's rings, [fx_ring_cap][n] (slot-major)
+    int fx_ring_cap;
 };
+
+enum FxKind : int { FX_NONE = 0, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY };
+// device parameter rows per stage: GAIN gain | TRANSFORM scale, offset | TANH drive |
+// TREMOLO rate, depth, duty, b0, a1 (one-pole design done on the host, effects.py:124-125) |
+// DELAY length (samples), feedback, drywet
+constexpr int kFxSlots = 6;
 
 enum ModTarget : int { MT_NONE = 0, MT_FM = 1, MT_FREQUENCY = 2, MT_DUTY = 3 };
 constexpr int kGridPoints = 1000;

@@ -389,6 +389,13 @@ struct klmi_bank {
     DevBuf<double> duty, env_coef, gain_l, gain_r;
     DevBuf<int32_t> wave;
     DevBuf<uint32_t> env_flags;
+    int f64_slots = 0;                   // rows of the float64 state slab
+    // effect stages (desc.n_fx > 0): parameters as the blocks take them [8][4][n] on the
+    // host, what the kernel needs [8][kFxSlots][n] on the device, the delay stage's rings
+    std::vector<double> fx_raw;
+    DevBuf<double> fx_par, fx_ring, fx_ring_backup;
+    int fx_ring_cap = 0;                 // slots per voice; 0 = not allocated yet
+    int fx_delay_stage = -1;
     DevBuf<double> lfo_par, mod_par;    // [3][n] frequency, scale, offset (allocated when used)
     DevBuf<int32_t> lfo_wave, mod_wave;
     // device state: one slab so that a preview can snapshot/restore it with two copies
@@ -433,7 +440,8 @@ struct klmi_bank {
     uint32_t *u32(int slot) { return state_u32.p + (size_t)slot * n; }
 };
 
-enum { SL_PHASE = 0, SL_ENV_VALUE, SL_Z0, SL_Z1, SL_FREQ, SL_AMP, SL_LFO_PHASE, SL_MOD_PHASE, SL_F64_COUNT };
+enum { SL_PHASE = 0, SL_ENV_VALUE, SL_Z0, SL_Z1, SL_FREQ, SL_AMP, SL_LFO_PHASE, SL_MOD_PHASE, SL_F64_COUNT,
+       SL_FX_STATE = SL_F64_COUNT };  // banks with effect stages: + [8][2] slots of stage state
 enum { SL_ENV_STATE = 0, SL_COEF_INDEX, SL_EV_CURSOR, SL_U32_COUNT };
 
 static BankView make_view(klmi_bank *b)
@@ -471,6 +479,13 @@ static BankView make_view(klmi_bank *b)
     v.mod_par = b->mod_par.p;
     v.mod_wave = b->mod_wave.p;
     v.mod_phase = b->f64(SL_MOD_PHASE);
+    v.n_fx = b->desc.n_fx;
+    for (int i = 0; i < KLMI_MAX_FX; ++i)
+        v.fx_kind[i] = i < b->desc.n_fx ? b->desc.fx[i] : 0;
+    v.fx_par = b->fx_par.p;
+    v.fx_state = b->desc.n_fx ? b->f64(SL_FX_STATE) : nullptr;
+    v.fx_ring = b->fx_ring.p;
+    v.fx_ring_cap = b->fx_ring_cap;
     return v;
 }
 
@@ -528,6 +543,66 @@ static int fill_device(klmi_bank *b, T *dst, size_t count, T value)
     return 0;
 }
 
+// Device parameters of one effect stage for voices [first, first+count), derived from the
+// host shadow (what the blocks take) exactly like the reference derives them.
+static int upload_fx(klmi_bank *b, int stage, int first, int count)
+{
+    const size_t n = (size_t)b->n;
+    const int kind = b->desc.fx[stage];
+    std::vector<double> dev((size_t)kFxSlots * count, 0.);
+    auto raw = [&](int k, int i) { return b->fx_raw[((size_t)stage * 4 + k) * n + first + i]; };
+    for (int i = 0; i < count; ++i) {
+        double d[kFxSlots] = {raw(0, i), raw(1, i), raw(2, i), raw(3, i), 0., 0.};
+        if (kind == KLMI_FX_TREMOLO) {
+            // effects.py:124-125: decay = max(1e-6, smoothness * min(duty, 1 - duty));
+            // coeffs = low_pass_coefficients(1. / decay)
+            const double duty = raw(3, i);
+            double decay = raw(2, i) * std::min(duty, 1. - duty);
+            if (!(decay > 1e-6))
+                decay = 1e-6;
+            double lb[1], la[2];
+            (void)klmi_low_pass_coefficients(1. / decay, lb, la);
+            d[2] = duty, d[3] = lb[0], d[4] = la[1];  // rate, depth, duty, b0, a1
+        } else if (kind == KLMI_FX_DELAY) {
+            d[0] = (double)(int)(raw(0, i) * KLMI_SAMPLING_RATE);  // effects.py:155 length
+        }
+        for (int k = 0; k < kFxSlots; ++k)
+            dev[(size_t)k * count + i] = d[k];
+    }
+    for (int k = 0; k < kFxSlots; ++k)
+        HIP_TRY(hipMemcpyAsync(b->fx_par.p + ((size_t)stage * kFxSlots + k) * n + first,
+                               &dev[(size_t)k * count], sizeof(double) * count,
+                               hipMemcpyHostToDevice, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+// The delay stage's rings [capacity][n], capacity = the longest line of the bank;
+// (re)allocated zeroed when the capacity changed (ring_buffer.py:42 zero-initialised).
+static int ensure_fx_ring(klmi_bank *b)
+{
+    if (b->fx_delay_stage < 0)
+        return 0;
+    const size_t n = (size_t)b->n;
+    int cap = 0;
+    for (size_t v = 0; v < n; ++v)
+        cap = std::max(cap, (int)(b->fx_raw[((size_t)b->fx_delay_stage * 4) * n + v] *
+                                  KLMI_SAMPLING_RATE));
+    if (cap == b->fx_ring_cap)
+        return 0;
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    b->fx_ring.release();
+    b->fx_ring_backup.release();
+    hipError_t e = b->fx_ring.alloc((size_t)cap * n);
+    if (e != hipSuccess)
+        return fail(KLMI_E_MEMORY, "delay lines (%d samples x %d voices) do not fit: %s", cap, b->n,
+                    hipGetErrorString(e));
+    HIP_TRY(hipMemset(b->fx_ring.p, 0, sizeof(double) * (size_t)cap * n));
+    HIP_TRY(hipMemset(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage), 0, sizeof(double) * n));
+    b->fx_ring_cap = cap;
+    return 0;
+}
+
 static int bank_init_reverb(klmi_bank *b);
 
 extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_desc *desc,
@@ -546,6 +621,23 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         return fail(KLMI_E_ARG, "klmi_bank_create: cutoff_lfo needs has_filter");
     if (desc->mod_target < KLMI_MOD_NONE || desc->mod_target > KLMI_MOD_DUTY)
         return fail(KLMI_E_ARG, "klmi_bank_create: unknown mod_target %d", desc->mod_target);
+    if (desc->n_fx < 0 || desc->n_fx > KLMI_MAX_FX)
+        return fail(KLMI_E_ARG, "klmi_bank_create: n_fx %d outside 0..%d", desc->n_fx, KLMI_MAX_FX);
+    {
+        int seen[KLMI_FX_DELAY + 1] = {};
+        for (int i = 0; i < desc->n_fx; ++i) {
+            if (desc->fx[i] < KLMI_FX_FILTER || desc->fx[i] > KLMI_FX_DELAY)
+                return fail(KLMI_E_ARG, "klmi_bank_create: unknown effect kind %d at stage %d",
+                            desc->fx[i], i);
+            seen[desc->fx[i]]++;
+        }
+        if (seen[KLMI_FX_FILTER] > 1 || seen[KLMI_FX_TREMOLO] > 1 || seen[KLMI_FX_DELAY] > 1)
+            return fail(KLMI_E_ARG, "klmi_bank_create: at most one Filter, one Tremolo and one "
+                                    "Delay stage per chain");
+        if (desc->n_fx && (seen[KLMI_FX_FILTER] != 0) != (desc->has_filter != 0))
+            return fail(KLMI_E_ARG, "klmi_bank_create: has_filter and a KLMI_FX_FILTER stage go "
+                                    "together");
+    }
     klmi_bank *b = new klmi_bank;
     b->ctx = ctx;
     b->n = n_voices;
@@ -574,9 +666,10 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     chk(b->gain_r.alloc(n));
     chk(b->wave.alloc(n));
     chk(b->env_flags.alloc(n));
-    chk(b->state_f64.alloc(SL_F64_COUNT * n));
+    b->f64_slots = SL_F64_COUNT + (desc->n_fx ? 2 * KLMI_MAX_FX : 0);
+    chk(b->state_f64.alloc(b->f64_slots * n));
     chk(b->state_u32.alloc(SL_U32_COUNT * n));
-    chk(b->backup_f64.alloc(SL_F64_COUNT * n));
+    chk(b->backup_f64.alloc(b->f64_slots * n));
     chk(b->backup_u32.alloc(SL_U32_COUNT * n));
     if (desc->cutoff_lfo) {
         chk(b->lfo_par.alloc(3 * n));
@@ -586,6 +679,8 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         chk(b->mod_par.alloc(3 * n));
         chk(b->mod_wave.alloc(n));
     }
+    if (desc->n_fx)
+        chk(b->fx_par.alloc((size_t)KLMI_MAX_FX * kFxSlots * n));
     chk(b->ev_offset.alloc(n + 1));
     chk(b->ev_block.alloc(1));
     chk(b->ev_kind.alloc(1));
@@ -602,7 +697,7 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         if (rc == 0)
             rc = r;
     };
-    if (hipMemset(b->state_f64.p, 0, sizeof(double) * SL_F64_COUNT * n) != hipSuccess ||
+    if (hipMemset(b->state_f64.p, 0, sizeof(double) * b->f64_slots * n) != hipSuccess ||
         hipMemset(b->state_u32.p, 0, sizeof(uint32_t) * SL_U32_COUNT * n) != hipSuccess ||
         hipMemset(b->ev_offset.p, 0, sizeof(uint32_t) * (n + 1)) != hipSuccess ||
         hipMemset(b->wave.p, 0, sizeof(int32_t) * n) != hipSuccess)
@@ -624,6 +719,22 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         step(fill_device<double>(b, b->mod_par.p + n, n, 1.));
         step(fill_device<double>(b, b->mod_par.p + 2 * n, n, 0.));
         step(fill_device<int32_t>(b, b->mod_wave.p, n, KLMI_WAVE_SINE));
+    }
+    if (desc->n_fx) {
+        // the blocks' own defaults (effects.py:62, 89-90, 143, 473; Transformer: identity)
+        static const double defaults[KLMI_FX_DELAY + 1][4] = {
+            {0, 0, 0, 0}, {0, 0, 0, 0}, {1., 0, 0, 0}, {1., 0., 0, 0}, {1., 0, 0, 0},
+            {0, 0, 0, 0}, {3., .8, 1., .5}, {1., .1, .5, 0}};
+        b->fx_raw.assign((size_t)KLMI_MAX_FX * 4 * n, 0.);
+        for (int st = 0; st < desc->n_fx; ++st) {
+            for (int k = 0; k < 4; ++k)
+                std::fill_n(b->fx_raw.begin() + ((size_t)st * 4 + k) * n, n,
+                            defaults[desc->fx[st]][k]);
+            if (desc->fx[st] == KLMI_FX_DELAY)
+                b->fx_delay_stage = st;
+            if (rc == 0)
+                step(upload_fx(b, st, 0, n_voices));
+        }
     }
     if (rc == 0)
         step(upload_env(b, 0, n_voices));
@@ -684,9 +795,13 @@ static int check_range(klmi_bank *b, int first, int count, const void *host, con
     return 0;
 }
 
-static int state_slot(int field, bool *is_u32)
+static int state_slot(klmi_bank *b, int field, bool *is_u32)
 {
     *is_u32 = false;
+    if (field >= KLMI_F_FX_STATE(0, 0) && field < KLMI_F_FX_STATE(KLMI_MAX_FX, 0))
+        return (field - KLMI_F_FX_STATE(0, 0)) / 2 < b->desc.n_fx
+                   ? SL_FX_STATE + (field - KLMI_F_FX_STATE(0, 0))
+                   : -1;
     switch (field) {
     case KLMI_F_PHASE: return SL_PHASE;
     case KLMI_F_ENV_VALUE: return SL_ENV_VALUE;
@@ -710,6 +825,23 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
     if (count == 0)
         return 0;
     hipStream_t st = b->ctx->stream;
+    if (field >= KLMI_F_FX(0, 0) && field < KLMI_F_FX(KLMI_MAX_FX, 0)) {
+        const int stage = (field - KLMI_F_FX(0, 0)) / 4, k = (field - KLMI_F_FX(0, 0)) % 4;
+        if (stage >= b->desc.n_fx)
+            return fail(KLMI_E_ARG, "klmi_bank_set_params: the chain has %d effect stage(s), "
+                                    "stage %d addressed", b->desc.n_fx, stage);
+        if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0) {
+            for (int i = 0; i < count; ++i) {
+                if (host[i] > 2.)  // effects.py:140, 160-164
+                    return fail(KLMI_E_ARG, "Delay time %.3f sec to long (max %.3f)!", host[i], 2.);
+                if (!((int)(host[i] * KLMI_SAMPLING_RATE) >= KLMI_BUFFER_SIZE))
+                    return fail(KLMI_E_ARG, "klmi_bank_set_params: delay time %g s is shorter than "
+                                            "one buffer (%d samples)", host[i], KLMI_BUFFER_SIZE);
+            }
+        }
+        std::copy(host, host + count, b->fx_raw.begin() + ((size_t)stage * 4 + k) * b->n + first);
+        return upload_fx(b, stage, first, count);
+    }
     switch (field) {
     case KLMI_F_FREQUENCY:
     case KLMI_F_AMPLITUDE: {
@@ -828,7 +960,7 @@ extern "C" int klmi_bank_state_get(klmi_bank *b, int field, int first, int count
     TRY(check_range(b, first, count, host, "klmi_bank_state_get"));
     TRY(use(b->ctx));
     bool is_u32;
-    const int slot = state_slot(field, &is_u32);
+    const int slot = state_slot(b, field, &is_u32);
     if (slot < 0)
         return fail(KLMI_E_ARG, "klmi_bank_state_get: field %d is not a state field", field);
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -851,7 +983,7 @@ extern "C" int klmi_bank_state_set(klmi_bank *b, int field, int first, int count
     TRY(check_range(b, first, count, host, "klmi_bank_state_set"));
     TRY(use(b->ctx));
     bool is_u32;
-    const int slot = state_slot(field, &is_u32);
+    const int slot = state_slot(b, field, &is_u32);
     if (slot < 0)
         return fail(KLMI_E_ARG, "klmi_bank_state_set: field %d is not a state field", field);
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -1048,7 +1180,8 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
                                  int first, int count, int block_base, uint32_t clock_base,
                                  int n_blocks, int span_total, float *partial, void *out)
 {
-    if (view.mod_target != MT_NONE)
+    const bool plain_chain = view.n_fx == 0 || (view.n_fx == 1 && view.fx_kind[0] == FX_FILTER);
+    if (view.mod_target != MT_NONE || !plain_chain)
         return launch_mod<MODE>(env, filt, st, view, first, count, block_base, clock_base, n_blocks,
                                 span_total, partial, out);
     if (env && filt)
@@ -1102,6 +1235,7 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix)
         return fail(KLMI_E_ARG, "klmi_bank_render: n_blocks must be positive, got %d", n_blocks);
     TRY(check_external(b, n_blocks));
     TRY(sync_events(b));
+    TRY(ensure_fx_ring(b));
     if (b->desc.has_reverb)
         return render_reverb(b, n_blocks, dev_mix);
     hipStream_t st = b->ctx->stream;
@@ -1185,9 +1319,19 @@ static int render_preview(klmi_bank *b, int first, int count, int n_blocks, void
                                   "available; use klmi_bank_render");
     TRY(check_external(b, n_blocks));
     TRY(sync_events(b));
+    TRY(ensure_fx_ring(b));
     hipStream_t st = b->ctx->stream;
     const size_t n = (size_t)b->n;
-    HIP_TRY(hipMemcpyAsync(b->backup_f64.p, b->state_f64.p, sizeof(double) * SL_F64_COUNT * n,
+    const size_t ring_len = (size_t)b->fx_ring_cap * n;
+    if (ring_len) {  // the delay lines are state too
+        if (ring_len * sizeof(double) > ((size_t)1 << 30))
+            return fail(KLMI_E_STATE, "klmi_bank_render_voices: previews of banks with more than "
+                                      "1 GiB of delay lines are not available");
+        HIP_TRY(b->fx_ring_backup.reserve(ring_len));
+        HIP_TRY(hipMemcpyAsync(b->fx_ring_backup.p, b->fx_ring.p, sizeof(double) * ring_len,
+                               hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(b->backup_f64.p, b->state_f64.p, sizeof(double) * b->f64_slots * n,
                            hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(b->backup_u32.p, b->state_u32.p, sizeof(uint32_t) * SL_U32_COUNT * n,
                            hipMemcpyDeviceToDevice, st));
@@ -1201,10 +1345,13 @@ static int render_preview(klmi_bank *b, int first, int count, int n_blocks, void
         return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
     HIP_TRY(hipEventRecord(b->ev_stop[0], st));
     b->timed_launches = 1;
-    HIP_TRY(hipMemcpyAsync(b->state_f64.p, b->backup_f64.p, sizeof(double) * SL_F64_COUNT * n,
+    HIP_TRY(hipMemcpyAsync(b->state_f64.p, b->backup_f64.p, sizeof(double) * b->f64_slots * n,
                            hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(b->state_u32.p, b->backup_u32.p, sizeof(uint32_t) * SL_U32_COUNT * n,
                            hipMemcpyDeviceToDevice, st));
+    if (ring_len)
+        HIP_TRY(hipMemcpyAsync(b->fx_ring.p, b->fx_ring_backup.p, sizeof(double) * ring_len,
+                               hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

@@ -1,5 +1,7 @@
-// mod_kernels.h -- voice chains whose oscillator has an audio-rate modulation input
-// (SURVEY 8f rank 1), for gfx950:
+// mod_kernels.h -- the general voice-chain kernel for gfx950: chains whose oscillator has an
+// audio-rate modulation input and/or effect stages between the voice and
+// the mixer (rank 2: Gain, Transformer, TanhDistortion, OctaveDistortion, Tremolo, Delay in
+// patch order, the Filter among them; klang/audio/effects.py:58-174, 452-561).  Modulation:
 //   MT_FM         FmOscillator (oscillators.py:193-234):
 //                  wave(phase + intensity * Oscillator(modFrequency, mod wave))
 //   MT_FREQUENCY  Lfo(shape=256) | Oscillator.frequency: the array branch of sample_phase
@@ -50,10 +52,13 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     double phase = bk.phase[v];
 
     const int target = bk.mod_target;  // uniform over the launch
-    const double mod_freq = bk.mod_par[v], mod_scale = bk.mod_par[n + v],
-                 mod_offset = bk.mod_par[2 * n + v];
-    const int mod_wave = bk.mod_wave[v];
-    double mod_phase = bk.mod_phase[v];
+    double mod_freq = 0., mod_scale = 0., mod_offset = 0., mod_phase = 0.;
+    int mod_wave = 0;
+    if (target != MT_NONE) {
+        mod_freq = bk.mod_par[v], mod_scale = bk.mod_par[n + v], mod_offset = bk.mod_par[2 * n + v];
+        mod_wave = bk.mod_wave[v];
+        mod_phase = bk.mod_phase[v];
+    }
 
     EnvParams ep{};
     EnvState es{};
@@ -86,6 +91,25 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     }
     const bool cutoff_lfo = has_filter && bk.lfo_par != nullptr;
     double lfo_ph = cutoff_lfo ? bk.lfo_phase[v] : 0.;
+
+    // effect stages: at most one Tremolo and one Delay per chain, so their state is scalar
+    int trem_stage = -1, delay_stage = -1;
+    for (int s = 0; s < bk.n_fx; ++s) {
+        if (bk.fx_kind[s] == FX_TREMOLO)
+            trem_stage = s;
+        if (bk.fx_kind[s] == FX_DELAY)
+            delay_stage = s;
+    }
+    double trem_phase = 0., trem_z = 0.;
+    if (trem_stage >= 0) {
+        trem_phase = bk.fx_state[(size_t)(2 * trem_stage) * n + v];
+        trem_z = bk.fx_state[(size_t)(2 * trem_stage + 1) * n + v];
+    }
+    int delay_pos = 0, delay_len = 1;
+    if (delay_stage >= 0) {
+        delay_pos = (int)bk.fx_state[(size_t)(2 * delay_stage) * n + v];
+        delay_len = (int)bk.fx_par[(size_t)(delay_stage * kFxSlots) * n + v];
+    }
 
     double gl = 0., gr = 0.;
     if (MIX) {
@@ -130,18 +154,26 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         const double mod_omega = kTau * mod_freq;
         const double mod_start = mod_phase;
         double running = 0.;                        // np.cumsum(frequency) within this block
+        const double trem_start = trem_phase;
 
         for (int c = 0; c < NCHUNK; ++c) {
             const int s0 = b * kBlock + c * CH;
             for (int i = 0; i < CH; ++i) {
                 const double t = c_time[c * CH + i];
                 // the modulator's sample: Oscillator.sample / Lfo.sample with shape 256
-                double m = wave_eval_any(mod_wave, np_mod_tau(mod_omega * t + mod_start), kPi);
-                if (target != MT_FM)
-                    m = mod_scale * m + mod_offset;
+                double m = 0.;
+                if (target != MT_NONE) {
+                    m = wave_eval_any(mod_wave, np_mod_tau(mod_omega * t + mod_start), kPi);
+                    if (target != MT_FM)
+                        m = mod_scale * m + mod_offset;
+                }
                 double x;
                 if (wave_id == W_ONE) {
                     x = 1.;
+                } else if (wave_id == W_EXTERNAL) {
+                    x = bk.ext_input[(size_t)(block_base * kBlock + s0 + i) * n + v];
+                } else if (target == MT_NONE) {
+                    x = wave_eval_any(wave_id, np_mod_tau(omega * t + start), duty_edge);
                 } else if (target == MT_FM) {
                     const double p = np_mod_tau(omega * t + start);
                     x = wave_eval_any(wave_id, p + mod_scale * m, duty_edge);
@@ -156,15 +188,67 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                 }
                 if (has_env)
                     x = amp * x * es.step(ep);
-                if (has_filter)
-                    x = bq.step(x);
+                if (bk.n_fx == 0) {
+                    if (has_filter)
+                        x = bq.step(x);
+                } else {
+                    for (int s = 0; s < bk.n_fx; ++s) {  // wave-uniform program
+                        const double *par = bk.fx_par + (size_t)(s * kFxSlots) * n + v;
+                        switch (bk.fx_kind[s]) {
+                        case FX_FILTER:
+                            x = bq.step(x);
+                            break;
+                        case FX_GAIN:       // effects.py:67-70
+                            x = par[0] * x;
+                            break;
+                        case FX_TRANSFORM:  // effects.py:558-561
+                            x = par[0] * x + par[n];
+                            break;
+                        case FX_TANH:       // effects.py:480-483
+                            x = tanh(par[0] * x);
+                            break;
+                        case FX_OCTAVE:     // effects.py:460-462
+                            x = 2. * (x * x) - 1.;
+                            break;
+                        case FX_TREMOLO: {  // effects.py:117-133
+                            const double rate = par[0], depth = par[n], duty = par[2 * n];
+                            const double b0 = par[3 * n], a1 = par[4 * n];
+                            const double p = np_mod_tau(kTau * rate * t + trem_start);
+                            const double pwm = (p < kTau * duty) ? 1. : -1.;
+                            const double y = trem_z + b0 * pwm;   // lfilter([b0], [1, a1])
+                            trem_z = 0. * pwm - a1 * y;
+                            x = ((1. - depth) + depth * (.5 + .5 * y)) * x;
+                            break;
+                        }
+                        case FX_DELAY: {    // effects.py:166-174 (the blend reads the window
+                                            // after the write: wet = new + feedback * delayed)
+                            int idx = delay_pos + c * CH + i;
+                            idx = idx >= delay_len ? idx - delay_len : idx;  // length >= one buffer
+                            double *slot = bk.fx_ring + (size_t)idx * n + v;
+                            const double w = x + par[n] * *slot;
+                            if (live)
+                                *slot = w;
+                            x = (1. - par[2 * n]) * x + par[2 * n] * w;
+                            break;
+                        }
+                        default:
+                            break;
+                        }
+                    }
+                }
                 emit_sample<MODE>(tile, i, lane, x, gl, gr, live, out, s0, count, local);
             }
             flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
         }
         // next start phases: sample 256 of this block
-        mod_phase = np_mod_tau(mod_omega * c_time[kBlock] + mod_start);
-        if (wave_id != W_ONE) {
+        if (trem_stage >= 0)
+            trem_phase = np_mod_tau(kTau * bk.fx_par[(size_t)(trem_stage * kFxSlots) * n + v] *
+                                        c_time[kBlock] + trem_start);
+        if (delay_stage >= 0)
+            delay_pos = (delay_pos + kBlock) % delay_len;
+        if (target != MT_NONE)
+            mod_phase = np_mod_tau(mod_omega * c_time[kBlock] + mod_start);
+        if (wave_id != W_ONE && wave_id != W_EXTERNAL) {
             if (target == MT_FREQUENCY)
                 phase = np_mod_tau((kTau * kDt) * running + start);
             else
@@ -174,7 +258,8 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
 
     if (live) {
         bk.phase[v] = phase;
-        bk.mod_phase[v] = mod_phase;
+        if (target != MT_NONE)
+            bk.mod_phase[v] = mod_phase;
         bk.frequency_rw[v] = freq;
         bk.amplitude_rw[v] = amp;
         if (has_env) {
@@ -188,6 +273,12 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             if (cutoff_lfo)
                 bk.lfo_phase[v] = lfo_ph;
         }
+        if (trem_stage >= 0) {
+            bk.fx_state[(size_t)(2 * trem_stage) * n + v] = trem_phase;
+            bk.fx_state[(size_t)(2 * trem_stage + 1) * n + v] = trem_z;
+        }
+        if (delay_stage >= 0)
+            bk.fx_state[(size_t)(2 * delay_stage) * n + v] = (double)delay_pos;
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
     }
 }

@@ -27,6 +27,19 @@ F_LFO_FREQUENCY, F_LFO_WAVE, F_LFO_SCALE, F_LFO_OFFSET, F_MOD_FREQUENCY, F_MOD_W
 F_PHASE, F_ENV_VALUE, F_ENV_STAGE, F_ENV_ENABLED, F_Z0, F_Z1, F_LFO_PHASE, F_MOD_PHASE = \
     range(32, 40)
 MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)   # klmi_mod_target
+# klmi_fx_kind, KLMI_F_FX / KLMI_F_FX_STATE
+FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY = range(8)
+MAX_FX = 8
+
+
+def F_FX(stage, k):
+    """Field id of parameter k (0..3) of effect stage `stage`."""
+    return 64 + 4 * stage + k
+
+
+def F_FX_STATE(stage, k):
+    """Field id of state value k (0..1) of effect stage `stage`."""
+    return 128 + 2 * stage + k
 
 WAVE_SINE, WAVE_SQUARE, WAVE_SAWTOOTH, WAVE_TRIANGLE, WAVE_PWM, WAVE_ONE, WAVE_EXTERNAL = range(7)
 EV_NOTE_OFF, EV_NOTE_ON, EV_SET_CUTOFF, EV_SET_FREQUENCY = range(4)
@@ -56,7 +69,7 @@ class ChainDesc(C.Structure):
                 ('pan_law', C.c_double), ('reverb_decay', C.c_double),
                 ('reverb_pre_delay', C.c_double), ('reverb_dry_wet', C.c_double),
                 ('reverb_n_echos', C.c_int32), ('cutoff_lfo', C.c_int32),
-                ('mod_target', C.c_int32), ('reserved', C.c_int32)]
+                ('mod_target', C.c_int32), ('n_fx', C.c_int32), ('fx', C.c_uint8 * 8)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -265,13 +278,18 @@ class Bank:
 
     def __init__(self, ctx, n_voices, has_env=True, has_filter=False, has_reverb=False,
                  stereo=False, pan_mode='constant_power', pan_law=None, reverb=None,
-                 cutoff_lfo=False, mod_target=MOD_NONE):
+                 cutoff_lfo=False, mod_target=MOD_NONE, effects=()):
         reverb = reverb or {}
+        effects = [int(k) for k in effects]
+        if len(effects) > MAX_FX:
+            raise ValueError('at most %d effect stages per chain' % MAX_FX)
         self.desc = ChainDesc(int(has_env), int(has_filter), int(has_reverb), int(stereo),
                               PAN_MODES[pan_mode], int(pan_law is not None), float(pan_law or 0.),
                               float(reverb.get('decay', 1.5)), float(reverb.get('pre_delay', .03)),
                               float(reverb.get('dry_wet', .7)), int(reverb.get('n_echos', 10)),
-                              int(cutoff_lfo), int(mod_target), 0)
+                              int(cutoff_lfo), int(mod_target), len(effects),
+                              (C.c_uint8 * 8)(*(effects + [0] * (MAX_FX - len(effects)))))
+        self.effects = effects
         self.ctx = ctx
         self.n = int(n_voices)
         self.channels = 2 if stereo else 1

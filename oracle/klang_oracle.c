@@ -506,6 +506,27 @@ void ko_stereo_mixer(const double *inputs, const double *gains, const double *pa
             out[i] = out[i] / (double)n;
 }
 
+/* Filter.update for one voice and one block (effects.py:371-385), with the optional
+ * Lfo(shape=1) on Filter.frequency (oscillators.py:175-181, effects.py:271-274, 365-373). */
+static void ko_filter_stage(ko_bank *bk, int v, double *buf)
+{
+    if (bk->cutoff_lfo) {
+        const double p = bk->lfo_phase[v];
+        double w;
+        bk->lfo_phase[v] = ko_phasor_step(bk->lfo_frequency[v], p);
+        ko_wave(bk->lfo_wave[v], &p, 1, .5, &w);
+        const double cutoff = bk->lfo_scale[v] * w + bk->lfo_offset[v];
+        bk->coef_index[v] = ko_filter_grid_index(bk->grid, KO_GRID_POINTS, cutoff);
+    }
+    const double *c = bk->coef_table + 5 * (size_t)bk->coef_index[v];
+    const double b[3] = {c[0], c[1], c[2]};
+    const double a[3] = {1., c[3], c[4]};
+    double z[2] = {bk->z0[v], bk->z1[v]};
+    ko_lfilter2(b, a, buf, KO_BUFFER_SIZE, z, buf);
+    bk->z0[v] = z[0];
+    bk->z1[v] = z[1];
+}
+
 /* ------------------------------------------------------------------------ */
 /* One voice, one block: voices.py:55-74 (note handling + (amp*osc)*env),
  * oscillators.py:130-133, envelopes.py:40-45, effects.py:371-385. */
@@ -547,24 +568,71 @@ static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
         for (int i = 0; i < KO_BUFFER_SIZE; ++i)
             buf[i] = bk->amplitude[v] * buf[i] * env[i];
     }
-    if (bk->has_filter) {
-        if (bk->cutoff_lfo) {
-            /* Lfo.sample with shape == SCALAR (oscillators.py:175-181), then
-             * Filter.update_frequency -> get_coefficients (effects.py:271-274, 365-373) */
-            const double p = bk->lfo_phase[v];
-            double w;
-            bk->lfo_phase[v] = ko_phasor_step(bk->lfo_frequency[v], p);
-            ko_wave(bk->lfo_wave[v], &p, 1, .5, &w);
-            const double cutoff = bk->lfo_scale[v] * w + bk->lfo_offset[v];
-            bk->coef_index[v] = ko_filter_grid_index(bk->grid, KO_GRID_POINTS, cutoff);
+    if (bk->n_fx == 0) {
+        if (bk->has_filter)
+            ko_filter_stage(bk, v, buf);
+        return;
+    }
+    const size_t n = (size_t)bk->n_voices;
+    for (int s = 0; s < bk->n_fx; ++s) {
+        const double *par = bk->fx_par + (size_t)s * 4 * n + v;     /* par[k * n] */
+        double *state = bk->fx_state + (size_t)s * 2 * n + v;
+        switch (bk->fx_kind[s]) {
+        case KO_FX_FILTER:
+            ko_filter_stage(bk, v, buf);
+            break;
+        case KO_FX_GAIN: /* effects.py:67-70 */
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                buf[i] = par[0] * buf[i];
+            break;
+        case KO_FX_TRANSFORM: /* effects.py:558-561 */
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                buf[i] = par[0] * buf[i] + par[n];
+            break;
+        case KO_FX_TANH: /* effects.py:480-483 */
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                buf[i] = tanh(par[0] * buf[i]);
+            break;
+        case KO_FX_OCTAVE: /* effects.py:460-462 */
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                buf[i] = 2. * (buf[i] * buf[i]) - 1.;
+            break;
+        case KO_FX_TREMOLO: { /* effects.py:117-133 */
+            const double rate = par[0], depth = par[n], smooth = par[2 * n], duty = par[3 * n];
+            const double lim = duty < 1. - duty ? duty : 1. - duty;
+            double decay = smooth * lim;
+            if (!(decay > 1e-6))
+                decay = 1e-6;
+            double b[1], a[2], pwm[KO_BUFFER_SIZE];
+            ko_low_pass_coefficients(1. / decay, b, a);
+            ko_sample_phase_const(rate, state[0], phase, &state[0]);
+            ko_wave(KO_WAVE_PWM, phase, KO_BUFFER_SIZE, duty, pwm);
+            ko_lfilter1(b, a, pwm, KO_BUFFER_SIZE, &state[n], pwm);
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+                const double e = (1. - depth) + depth * (.5 + .5 * pwm[i]);
+                buf[i] = e * buf[i];
+            }
+            break;
         }
-        const double *c = bk->coef_table + 5 * (size_t)bk->coef_index[v];
-        const double b[3] = {c[0], c[1], c[2]};
-        const double a[3] = {1., c[3], c[4]};
-        double z[2] = {bk->z0[v], bk->z1[v]};
-        ko_lfilter2(b, a, buf, KO_BUFFER_SIZE, z, buf);
-        bk->z0[v] = z[0];
-        bk->z1[v] = z[1];
+        case KO_FX_DELAY: { /* effects.py:166-174 + ring_buffer.py:62-107.  The window that
+            peek() returns is a view, so after extend() it holds new + feedback * old and
+            the blend's wet operand is that sum.  Valid while length >= one buffer. */
+            const int length = (int)(par[0] * KO_SAMPLING_RATE);
+            const double feedback = par[n], drywet = par[2 * n];
+            double *ring = bk->fx_ring + (size_t)v * bk->fx_ring_capacity;
+            int pos = (int)state[0];
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+                const int idx = (pos + i) % length;
+                const double w = buf[i] + feedback * ring[idx];
+                ring[idx] = w;
+                buf[i] = (1. - drywet) * buf[i] + drywet * w; /* math.py:68-75 blend */
+            }
+            state[0] = (double)((pos + KO_BUFFER_SIZE) % length);
+            break;
+        }
+        default:
+            break;
+        }
     }
 }
 

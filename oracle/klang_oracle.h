@@ -142,7 +142,26 @@ typedef struct {
     int mod_target;            /* KO_MOD_* below: one audio-rate modulator per voice */
     double *mod_frequency, *mod_scale, *mod_offset, *mod_phase /* state */;
     int32_t *mod_wave;
+    /* effect stages between the voice and the mixer, in patch order (effects.py:58-174,
+     * 452-561).  n_fx == 0: the chain is just [Filter] when has_filter. */
+    int n_fx;
+    int fx_kind[8];            /* KO_FX_* */
+    double *fx_par;            /* [8][4][n_voices] parameters as the blocks take them */
+    double *fx_state;          /* [8][2][n_voices]: tremolo lfo phase, zi; delay position */
+    double *fx_ring;           /* the delay stage's rings, [n_voices][fx_ring_capacity] */
+    int fx_ring_capacity;
 } ko_bank;
+
+enum {
+    KO_FX_NONE = 0,
+    KO_FX_FILTER = 1,     /* the bank's Filter (has_filter) at this position */
+    KO_FX_GAIN = 2,       /* p0 gain */
+    KO_FX_TRANSFORM = 3,  /* p0 scale, p1 offset */
+    KO_FX_TANH = 4,       /* p0 drive */
+    KO_FX_OCTAVE = 5,
+    KO_FX_TREMOLO = 6,    /* p0 rate, p1 depth, p2 smoothness, p3 dutyCycle */
+    KO_FX_DELAY = 7       /* p0 time (s), p1 feedback, p2 drywet; length >= one buffer */
+};
 
 enum {
     KO_MOD_NONE = 0,

@@ -71,7 +71,12 @@ class Bank(C.Structure):
         ('mod_target', C.c_int),
         ('mod_frequency', _dp), ('mod_scale', _dp), ('mod_offset', _dp), ('mod_phase', _dp),
         ('mod_wave', C.POINTER(C.c_int32)),
+        ('n_fx', C.c_int), ('fx_kind', C.c_int * 8),
+        ('fx_par', _dp), ('fx_state', _dp), ('fx_ring', _dp), ('fx_ring_capacity', C.c_int),
     ]
+
+
+FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY = range(8)
 
 
 MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)
@@ -367,6 +372,25 @@ class OracleBank:
         self.mod_frequency, self.mod_scale, self.mod_offset = np.ones(n), np.ones(n), np.zeros(n)
         self.mod_phase = np.zeros(n)
         self.mod_wave = np.zeros(n, dtype=np.int32)
+        # effect stages (none by default)
+        self.fx_kind = []
+        self.fx_par = np.zeros((8, 4, n))
+        self.fx_state = np.zeros((8, 2, n))
+        self.fx_ring = np.zeros((n, 1))
+
+    def set_effects(self, stages):
+        """stages: [(FX_* kind, p0, p1, p2, p3)], each p a scalar or [n] array."""
+        self.fx_kind = [int(st[0]) for st in stages]
+        self.fx_par[:] = 0.
+        self.fx_state[:] = 0.
+        for s, st in enumerate(stages):
+            for k, p in enumerate(st[1:]):
+                self.fx_par[s, k, :] = p
+            if st[0] == FX_DELAY:
+                lengths = (self.fx_par[s, 0] * 44100).astype(int)
+                if lengths.min() < BUFFER_SIZE:
+                    raise ValueError('delay shorter than one buffer')
+                self.fx_ring = np.zeros((self.n, int(lengths.max())))
 
     def set_envelope(self, i, attack, decay, sustain, release, overshoot=1e-3, retrigger=False,
                      loop=False):
@@ -400,7 +424,9 @@ class OracleBank:
                     _p(self.lfo_offset), _p(self.lfo_phase), self.lfo_wave.ctypes.data_as(ip),
                     _p(self.grid), int(self.mod_target), _p(self.mod_frequency),
                     _p(self.mod_scale), _p(self.mod_offset), _p(self.mod_phase),
-                    self.mod_wave.ctypes.data_as(ip))
+                    self.mod_wave.ctypes.data_as(ip),
+                    len(self.fx_kind), (C.c_int * 8)(*(self.fx_kind + [0] * (8 - len(self.fx_kind)))),
+                    _p(self.fx_par), _p(self.fx_state), _p(self.fx_ring), self.fx_ring.shape[1])
 
     def render(self, n_blocks, events=None, want_voices=False, n_threads=1):
         """events: structured array EVENT_DTYPE (any order; sorted here)."""

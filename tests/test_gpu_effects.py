@@ -1,0 +1,127 @@
+"""HIP path vs the reference's fixtures and vs the oracle for the effect stages of a voice
+chain: Gain, Transformer, TanhDistortion, OctaveDistortion, Tremolo,
+Delay, alone and chained around the Filter.  Everything goes through the C-ABI."""
+import numpy as np
+import pytest
+
+from klang_amd import patches as P
+from tests.helpers import B, library_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def saw_bank(hip, ctx, stages, n=1, **kw):
+    """stages: [(kind, p0, p1, ...)] -> bank of saw oscillators at 220 Hz."""
+    bank = hip.Bank(ctx, n, has_env=kw.pop('has_env', False), effects=[s[0] for s in stages], **kw)
+    bank.set(hip.F_WAVE, [hip.WAVE_SAWTOOTH] * n)
+    bank.set(hip.F_FREQUENCY, [220.] * n)
+    for s, st in enumerate(stages):
+        for k, p in enumerate(st[1:]):
+            bank.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    return bank
+
+
+@pytest.mark.parametrize('key,stage,n_blocks,tol', [
+    ('gain', ('FX_GAIN', .37), 24, 0.),
+    ('transformer', ('FX_TRANSFORM', .3, .1), 24, 0.),
+    ('tanh', ('FX_TANH', 2.), 24, 1e-15),             # device tanh vs NumPy's: a few ulp
+    ('octave', ('FX_OCTAVE',), 24, 0.),
+    ('tremolo', ('FX_TREMOLO', 3., .8, .5, .3), 60, 0.),
+    ('tremolo_square', ('FX_TREMOLO', 7., .5, 0., .5), 30, 0.),
+    ('delay', ('FX_DELAY', .01, .6, .4), 40, 0.),
+    ('delay_long', ('FX_DELAY', .0437, .9, .5), 40, 0.),
+])
+def test_effect_stage_vs_reference(hip, ctx, golden, key, stage, n_blocks, tol):
+    want = golden('effects')[key]
+    bank = saw_bank(hip, ctx, [(getattr(hip, stage[0]),) + stage[1:]])
+    got = bank.render_voices(n_blocks, f64=True)[0].reshape(n_blocks, B)   # preview
+    if tol:
+        assert np.abs(got - want).max() <= tol
+    else:
+        np.testing.assert_array_equal(got, want)
+    # the committing render in two launches carries the stage state and the delay line
+    k = n_blocks // 3
+    mix = np.concatenate([bank.render(k), bank.render(n_blocks - k)])[:, 0, :]
+    assert np.abs(mix - want).max() <= 1e-5 * max(1., np.abs(want).max())
+    if key == 'tremolo':
+        final = golden('effects')['tremolo_final']
+        assert bank.get_state(hip.F_FX_STATE(0, 0))[0] == final[0]
+        assert bank.get_state(hip.F_FX_STATE(0, 1))[0] == final[1]
+    if key == 'delay':
+        assert bank.get_state(hip.F_FX_STATE(0, 0))[0] == golden('effects')['delay_final_pos_length'][0]
+
+
+def test_effect_chain_after_a_voice_vs_reference(hip, ctx, golden):
+    """voice -> Filter -> TanhDistortion -> Tremolo -> Delay -> Gain with notes."""
+    want = golden('effects')['chain']
+    bank = saw_bank(hip, ctx, [(hip.FX_FILTER,), (hip.FX_TANH, 1.5), (hip.FX_TREMOLO, 5., .6, .4, .4),
+                               (hip.FX_DELAY, .02, .5, .3), (hip.FX_GAIN, .8)],
+                    has_env=True, has_filter=True)
+    for f, val in ((hip.F_ATTACK, .01), (hip.F_DECAY, .05), (hip.F_SUSTAIN, .6),
+                   (hip.F_RELEASE, .04), (hip.F_CUTOFF, 1500.)):
+        bank.set(f, [val])
+    bank.event(0, 0, hip.EV_NOTE_ON, .8, 220.)
+    bank.event(0, 10, hip.EV_NOTE_OFF)
+    bank.event(0, 14, hip.EV_NOTE_ON, .5, 329.6275569128699)
+    got = bank.render_voices(30, f64=True)[0].reshape(30, B)
+    assert np.abs(got - want).max() <= 1e-12     # closed-form vs scipy Butterworth row, tanh ulps
+    mix = np.concatenate([bank.render(7), bank.render(23)])[:, 0, :]
+    assert np.abs(mix - want).max() <= 1e-5
+
+
+def test_effect_chains_vs_oracle_many_voices(hip, ctx, oracle):
+    """600 voices (config-3 style notes) through Filter -> Octave -> Tremolo -> Delay ->
+    Transformer -> Gain with per-voice parameters: float64 streams equal the oracle's bit
+    for bit (no transcendental on the device side of this chain)."""
+    n, nb = 600, 12
+    rng = np.random.default_rng(21)
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=6)
+    stages = [(hip.FX_FILTER,), (hip.FX_OCTAVE,),
+              (hip.FX_TREMOLO, 1. + 9. * rng.random(n), rng.random(n), rng.random(n), .1 + .8 * rng.random(n)),
+              (hip.FX_DELAY, .006 + .05 * rng.random(n), .9 * rng.random(n), rng.random(n)),
+              (hip.FX_TRANSFORM, .5 + rng.random(n), rng.random(n) - .5), (hip.FX_GAIN, rng.random(n))]
+    table, grid = library_table(hip)
+    from tests.helpers import oracle_bank_from_patch
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.set_effects(stages)
+    hb = hip.Bank(ctx, n, has_env=True, has_filter=True, effects=[s[0] for s in stages])
+    hb.load_patch(patch)
+    for s, st in enumerate(stages):
+        for k, p in enumerate(st[1:]):
+            hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+    np.testing.assert_array_equal(hb.render_voices(nb, f64=True), want_voices)
+    mix = np.concatenate([hb.render(5), hb.render(7)])
+    assert np.abs(mix[:, 0, :] - want_mix[:, 0, :]).max() <= 1e-6
+    np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(2, 0)), ob.fx_state[2, 0])
+    np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(2, 1)), ob.fx_state[2, 1])
+    np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(3, 0)), ob.fx_state[3, 0])
+    np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
+
+
+def test_effect_argument_errors(hip, ctx):
+    with pytest.raises(hip.NativeError):
+        hip.Bank(ctx, 2, effects=[hip.FX_DELAY, hip.FX_DELAY])          # one Delay per chain
+    with pytest.raises(hip.NativeError):
+        hip.Bank(ctx, 2, has_filter=True, effects=[hip.FX_GAIN])        # Filter stage missing
+    with pytest.raises(hip.NativeError):
+        hip.Bank(ctx, 2, effects=[hip.FX_FILTER])                       # has_filter missing
+    with pytest.raises(hip.NativeError):
+        hip.Bank(ctx, 2, effects=[9])
+    bank = hip.Bank(ctx, 2, effects=[hip.FX_GAIN, hip.FX_DELAY])
+    with pytest.raises(hip.NativeError) as e:
+        bank.set(hip.F_FX(1, 0), [2.5, 1.])
+    assert 'to long' in str(e.value)                                    # effects.py:160-164
+    with pytest.raises(hip.NativeError):
+        bank.set(hip.F_FX(1, 0), [.001, 1.])                            # shorter than a buffer
+    with pytest.raises(hip.NativeError):
+        bank.set(hip.F_FX(2, 0), [1., 1.])                              # no such stage
+    with pytest.raises(hip.NativeError):
+        bank.get_state(hip.F_FX_STATE(5, 0))

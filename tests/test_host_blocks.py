@@ -243,3 +243,45 @@ def test_find_fusable_reports_what_it_cannot_fuse():
     shared.output.connect(Block(1, 0).input)      # second consumer
     _, errors = fusion.find_fusable(determine_execution_order([m]))
     assert any('more than one input' in e for e in errors)
+
+
+# ---- effects: host blocks vs the reference's fixtures ------------------------------
+def _run_effect(make, n_blocks, golden_key, golden, tol=0.):
+    from klang_amd.audio import Oscillator, sawtooth
+    from klang_amd.schedule import determine_execution_order
+    osc = Oscillator(frequency=220., wave_func=sawtooth)
+    blk = make()
+    osc | blk
+    order = determine_execution_order([blk])
+    outs = []
+    for _ in range(n_blocks):
+        for o in order:
+            o.update()
+        outs.append(np.array(blk.output.value, dtype=float))
+    want = golden('effects')[golden_key]
+    if tol:
+        np.testing.assert_allclose(np.array(outs), want, rtol=0, atol=tol)
+    else:
+        np.testing.assert_array_equal(np.array(outs), want)
+    return blk
+
+
+def test_effect_blocks_match_reference_fixtures(golden):
+    from klang_amd.audio import (Delay, Gain, OctaveDistortion, TanhDistortion, Transformer,
+                                 Tremolo)
+    _run_effect(lambda: Gain(.37), 24, 'gain', golden)
+    _run_effect(lambda: Transformer(.3, .1), 24, 'transformer', golden)
+    _run_effect(lambda: TanhDistortion(2.), 24, 'tanh', golden)
+    _run_effect(lambda: OctaveDistortion(), 24, 'octave', golden)
+    # the one-pole coefficients come from the library's exp (<= 1 ulp from math.exp)
+    trem = _run_effect(lambda: Tremolo(rate=3., depth=.8, smoothness=.5, dutyCycle=.3), 60,
+                       'tremolo', golden, tol=1e-13)
+    final = golden('effects')['tremolo_final']
+    assert trem.lfo.currentPhase == final[0] and abs(trem.zi[0] - final[1]) <= 1e-13
+    _run_effect(lambda: Tremolo(rate=7., depth=.5, smoothness=0., dutyCycle=.5), 30,
+                'tremolo_square', golden, tol=1e-13)
+    dl = _run_effect(lambda: Delay(time=.01, feedback=.6, drywet=.4), 40, 'delay', golden)
+    assert [dl.ring.pos, dl.ring.length] == list(golden('effects')['delay_final_pos_length'])
+    _run_effect(lambda: Delay(time=.0437, feedback=.9, drywet=.5), 40, 'delay_long', golden)
+    with pytest.raises(ValueError):
+        Delay(time=2.5)

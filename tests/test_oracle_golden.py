@@ -474,6 +474,61 @@ def test_audio_rate_lfo_into_duty_cycle(oracle, golden, wname):
         eq(got, want)
 
 
+# ---- effect stages -----------------------------------------------------------
+def _fx_bank(oracle, golden, stages, has_env=False, has_filter=False):
+    from klang_amd import patches as P
+    table, grid = _ref_table(golden)
+    bank = oracle.OracleBank(1, has_env, has_filter, False)
+    bank.coef_table = table
+    bank.grid = grid
+    bank.wave[:] = P.WAVE_SAWTOOTH
+    bank.frequency[:] = 220.
+    bank.set_effects(stages)
+    return bank
+
+
+@pytest.mark.parametrize('key,stage,n_blocks,tol', [
+    ('gain', ('FX_GAIN', .37), 24, 0.),
+    ('transformer', ('FX_TRANSFORM', .3, .1), 24, 0.),
+    ('tanh', ('FX_TANH', 2.), 24, 4e-16),            # glibc tanh vs NumPy's: <= 2 ulp
+    ('octave', ('FX_OCTAVE',), 24, 0.),
+    ('tremolo', ('FX_TREMOLO', 3., .8, .5, .3), 60, 0.),
+    ('tremolo_square', ('FX_TREMOLO', 7., .5, 0., .5), 30, 0.),
+    ('delay', ('FX_DELAY', .01, .6, .4), 40, 0.),
+    ('delay_long', ('FX_DELAY', .0437, .9, .5), 40, 0.),
+])
+def test_effect_stage(oracle, golden, key, stage, n_blocks, tol):
+    g = golden('effects')
+    bank = _fx_bank(oracle, golden, [(getattr(oracle, stage[0]),) + stage[1:]])
+    mix, _ = bank.render(n_blocks)
+    if tol:
+        np.testing.assert_allclose(mix[:, 0, :], g[key], rtol=0, atol=tol)
+    else:
+        eq(mix[:, 0, :], g[key])
+    if key == 'tremolo':
+        eq(bank.fx_state[0, :, 0], g['tremolo_final'])
+    if key == 'delay':
+        assert bank.fx_state[0, 0, 0] == g['delay_final_pos_length'][0]
+
+
+def test_effect_chain_after_a_voice(oracle, golden):
+    """voice -> Filter -> TanhDistortion -> Tremolo -> Delay -> Gain with notes."""
+    from klang_amd import patches as P
+    g = golden('effects')
+    table, grid = _ref_table(golden)
+    bank = _fx_bank(oracle, golden, [(oracle.FX_FILTER,), (oracle.FX_TANH, 1.5),
+                                     (oracle.FX_TREMOLO, 5., .6, .4, .4),
+                                     (oracle.FX_DELAY, .02, .5, .3), (oracle.FX_GAIN, .8)],
+                    has_env=True, has_filter=True)
+    bank.set_envelope(0, .01, .05, .6, .04)
+    bank.coef_index[:] = oracle.filter_grid_index(grid, 1500.)
+    ev = np.concatenate([P.make_events(0, 0, P.EV_NOTE_ON, .8, 220.),
+                         P.make_events(0, 10, P.EV_NOTE_OFF, 0., 220.),
+                         P.make_events(0, 14, P.EV_NOTE_ON, .5, 329.6275569128699)])
+    mix, _ = bank.render(30, ev)
+    np.testing.assert_allclose(mix[:, 0, :], g['chain'], rtol=0, atol=1e-15)
+
+
 def test_hello_world_blocks(oracle, golden):
     g = golden('hello_world')
     osc = oracle.OscillatorState(440., 'sine')

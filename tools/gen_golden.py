@@ -444,6 +444,49 @@ def main():
         mod['pwm_scale_offset'] = np.array([lfo.scale, lfo.offset])
     save('modulation', **mod)
 
+    # ---- element-wise and delay effects -----------------------
+    # effects.py:58-174, 452-561 on a saw oscillator, and one chain through all of them
+    fx = {}
+
+    def fx_run(make, n_blocks=24, wave=W.sawtooth, freq=220.):
+        osc = OSC.Oscillator(frequency=freq, wave_func=wave)
+        blk = make()
+        osc | blk
+        order = determine_execution_order([blk])
+        outs = []
+        for b in range(n_blocks):
+            for o in order:
+                o.update()
+            outs.append(np.array(blk.output.value, dtype=float))
+        return np.array(outs), blk
+
+    fx['gain'], _ = fx_run(lambda: FX.Gain(.37))
+    fx['transformer'], _ = fx_run(lambda: FX.Transformer(.3, .1))
+    fx['tanh'], _ = fx_run(lambda: FX.TanhDistortion(2.))
+    fx['octave'], _ = fx_run(lambda: FX.OctaveDistortion())
+    fx['tremolo'], trem = fx_run(lambda: FX.Tremolo(rate=3., depth=.8, smoothness=.5, dutyCycle=.3),
+                                 n_blocks=60)
+    fx['tremolo_final'] = np.array([trem.lfo.currentPhase, trem.zi[0]])
+    fx['tremolo_square'], _ = fx_run(lambda: FX.Tremolo(rate=7., depth=.5, smoothness=0., dutyCycle=.5),
+                                     n_blocks=30)
+    fx['delay'], dl = fx_run(lambda: FX.Delay(time=.01, feedback=.6, drywet=.4), n_blocks=40)
+    fx['delay_final_pos_length'] = np.array([dl.ring.pos, dl.ring.length])
+    fx['delay_long'], _ = fx_run(lambda: FX.Delay(time=.0437, feedback=.9, drywet=.5), n_blocks=40)
+
+    # voice -> Filter -> TanhDistortion -> Tremolo -> Delay -> Gain
+    voice = A.Voice(OSC.Oscillator(wave_func=W.sawtooth), A.ADSR(.01, .05, .6, .04))
+    stages = [FX.Filter(frequency=1500.), FX.TanhDistortion(1.5),
+              FX.Tremolo(rate=5., depth=.6, smoothness=.4, dutyCycle=.4),
+              FX.Delay(time=.02, feedback=.5, drywet=.3), FX.Gain(.8)]
+    blk = voice
+    for st in stages:
+        blk = blk | st
+    hooks = {0: [lambda: voice.input.push(Note(57, .8, frequency=220.))],
+             10: [lambda: voice.input.push(Note(57, 0., frequency=220.))],
+             14: [lambda: voice.input.push(Note(64, .5, frequency=329.6275569128699))]}
+    fx['chain'] = run_graph(stages[-1], 30, hooks)
+    save('effects', **fx)
+
     # ---- hello_world (config 1): Oscillator(440) | Dac, pre-normalisation ---
     osc = OSC.Oscillator(frequency=440.)
     blocks = []
