@@ -200,3 +200,63 @@ def test_modulator_state_is_copied_back_to_the_host_blocks(hip):
     for _ in range(10):
         twin.update()
     assert lfo.currentPhase == twin.currentPhase
+
+
+def _effect_patches():
+    from klang_amd.audio import (Delay, Gain, Lfo, OctaveDistortion, TanhDistortion, Transformer,
+                                 Tremolo, triangle)
+
+    def arpeggiator_like():   # examples/arpeggiator_demo.py:29-49: voice | fil | delay, Lfo on the cutoff
+        mixer = Mixer()
+        for k in range(3):
+            lfo = Lfo(frequency=1. + k, wave_func=triangle, outputRange=(100, 3000))
+            fil = Filter(frequency=220.)
+            lfo | fil.frequency
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+            voice.input.push(Note(0, .8, frequency=110. * (k + 1)))
+            mixer += voice | fil | Delay(time=.013 + .004 * k, feedback=.9)
+        mixer.gains = [1., .3, .5]
+        return mixer | Dac()
+
+    def tremolo_chain():      # examples/tempo_aware_effects.py style
+        osc = Oscillator(220., wave_func=sawtooth)
+        return osc | Tremolo(rate=6., depth=.7, smoothness=.3) | TanhDistortion(2.) | Gain(.5) | Dac()
+
+    def shaping():
+        mixer = Mixer()
+        for k in range(4):
+            mixer += (Oscillator(110. * (k + 1), wave_func=sine) | OctaveDistortion()
+                      | Transformer(.5, .1 * k) | Filter(frequency=800. + 300 * k))
+        return mixer | Dac()
+
+    return dict(arpeggiator_like=arpeggiator_like, tremolo_chain=tremolo_chain, shaping=shaping)
+
+
+@pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping'])
+def test_effect_patches_match_the_host_evaluation(hip, name):
+    build = _effect_patches()[name]
+    order, banks = fusion.compile_order(determine_execution_order([build()]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac']
+    for bank in banks:
+        bank.close()
+    dur = 24 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0.))
+    want = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert got.shape == want.shape and np.abs(want).max() > .05
+    assert np.abs(got - want).max() <= 1e-5
+
+
+def test_host_side_gain_edits_reach_the_device(hip):
+    from klang_amd.audio import Gain
+    gain = Gain(1.)
+    dac = Oscillator(220., wave_func=sawtooth) | gain | Dac()
+    order, banks = fusion.compile_order(determine_execution_order([dac]))
+    out = []
+    for b in range(6):
+        if b == 3:
+            gain.gain.set_value(.25)
+        for blk in order:
+            blk.update()
+        out.append(np.array(gain.output.value))
+    banks[0].close()
+    assert abs(np.abs(out[2]).max() - 1.) < 1e-2 and abs(np.abs(out[4]).max() - .25) < 1e-2

@@ -269,3 +269,47 @@ def test_fuser_recognises_modulation_sources():
     m2 += (Oscillator(330.) | f2)
     groups, errors = chains_of(m2)
     assert any('more than one input' in e for e in errors)
+
+
+def test_fuser_recognises_effect_stages():
+    from klang_amd import fusion, native
+    from klang_amd.audio import (ADSR, Delay, Filter, Gain, Lfo, Mixer, Oscillator, Reverb,
+                                 TanhDistortion, Tremolo, Voice, sawtooth)
+    from klang_amd.schedule import determine_execution_order
+
+    def build():   # examples/arpeggiator_demo.py:29-49 in small
+        voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.1, .2, .3, .4))
+        return voice | Filter(frequency=220.) | Delay(time=.076, feedback=.9) | Gain(.5)
+
+    mixer = Mixer()
+    mixer += build()
+    mixer += build()
+    groups, errors = fusion.find_fusable(determine_execution_order([mixer]))
+    assert not errors and len(groups) == 1
+    chain = groups[0][1][0]
+    assert chain.program == (native.FX_FILTER, native.FX_DELAY, native.FX_GAIN)
+    assert [type(b).__name__ for b in chain.blocks] == ['Voice', 'Filter', 'Delay', 'Gain']
+    # the plain [Filter] chain keeps the empty program (fast kernel)
+    plain = Oscillator() | Filter()
+    groups, _ = fusion.find_fusable(determine_execution_order([plain]))
+    assert groups[0][1][0].program == ()
+    # effects before a Reverb are fine, after it they are not
+    ok = Oscillator() | TanhDistortion(2.) | Reverb()
+    groups, errors = fusion.find_fusable(determine_execution_order([ok]))
+    assert not errors and groups[0][1][0].program == (native.FX_TANH,)
+    bad = Oscillator() | Reverb() | Gain(.5)
+    groups, errors = fusion.find_fusable(determine_execution_order([bad]))
+    assert errors
+    # refused: two delays, modulated gain, short delay
+    two = Oscillator() | Delay(.01) | Delay(.02)
+    _, errors = fusion.find_fusable(determine_execution_order([two]))
+    assert any('one Delay per chain' in e for e in errors)
+    gain = Gain(.5)
+    Lfo(1.) | gain.gain
+    _, errors = fusion.find_fusable(determine_execution_order([Oscillator() | gain]))
+    assert any('patched' in e for e in errors)
+    _, errors = fusion.find_fusable(determine_execution_order([Oscillator() | Delay(.001)]))
+    assert any('shorter than one buffer' in e for e in errors)
+    trem = Oscillator() | Tremolo(rate=4.)
+    groups, errors = fusion.find_fusable(determine_execution_order([trem]))
+    assert not errors and groups[0][1][0].program == (native.FX_TREMOLO,)

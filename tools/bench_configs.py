@@ -4,7 +4,7 @@ not bench.py's headline: config 2 (haunting patch, replicated), config 3 in
 materialised mode (per-voice float32 streams written to HBM) and config 4
 (reverb channels, delay lines in HBM).  Usage:
 
-    python tools/bench_configs.py [2] [3m] [4] [4big]
+    python tools/bench_configs.py [2] [3m] [3fm] [3fx] [3delay] [4] [4big]
 """
 import json
 import os
@@ -90,6 +90,37 @@ def config3_materialised(ctx):
                               algorithmic_bytes_per_voice_sample=4.594))
 
 
+def config3_general(ctx, label, **bank_kw):
+    """Config 3's patch through the general kernel (mod_kernels.h): with an FmOscillator
+    per voice, or with effect stages around the Filter."""
+    n, n_blocks = 65536, 128
+    patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=n_blocks, off_base=20, off_span=40)
+    bank = native.Bank(ctx, n, has_env=True, has_filter=True, **bank_kw)
+    ev = patch.events
+    p = patches.Patch(patch)
+    p['events'] = ev[:0]
+    bank.load_patch(p)
+    rng = np.random.default_rng(9)
+    if bank_kw.get('mod_target'):
+        bank.set(native.F_MOD_FREQUENCY, 20. + 200. * rng.random(n))
+        bank.set(native.F_MOD_SCALE, 2. * rng.random(n))
+        bank.set(native.F_MOD_WAVE, np.full(n, native.WAVE_SAWTOOTH))
+    for s, kind in enumerate(bank_kw.get('effects', ())):
+        if kind == native.FX_TREMOLO:
+            bank.set(native.F_FX(s, 0), 1. + 8. * rng.random(n))
+        elif kind == native.FX_DELAY:
+            bank.set(native.F_FX(s, 0), .006 + .01 * rng.random(n))
+        elif kind == native.FX_GAIN:
+            bank.set(native.F_FX(s, 0), rng.random(n))
+    queue(bank, ev, n_blocks, 5)
+    best, med = timed(lambda: bank.render(n_blocks))
+    ms, launches = bank.last_kernel_ms()
+    units = n * n_blocks * B
+    return dict(config='3 general kernel, %s: 65,536 voices x %d blocks' % (label, n_blocks),
+                value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
+                launches=launches)
+
+
 def config4(ctx, n_channels=4096, n_blocks=512):
     patch = patches.reverb_patch(n_channels=n_channels, n_blocks=n_blocks)
     bank, ev = bank_for(ctx, patch)
@@ -123,6 +154,14 @@ def main():
             r = config3_materialised(ctx)
         elif w == '4':
             r = config4(ctx)
+        elif w == '3fm':
+            r = config3_general(ctx, 'FmOscillator (saw modulator)', mod_target=native.MOD_FM)
+        elif w == '3fx':
+            r = config3_general(ctx, 'Filter -> Tremolo -> Gain',
+                                effects=[native.FX_FILTER, native.FX_TREMOLO, native.FX_GAIN])
+        elif w == '3delay':
+            r = config3_general(ctx, 'Filter -> Delay(6-16 ms) -> Gain',
+                                effects=[native.FX_FILTER, native.FX_DELAY, native.FX_GAIN])
         elif w == '4big':
             r = config4(ctx, 16384, 128)
         else:
