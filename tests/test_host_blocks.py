@@ -213,7 +213,7 @@ def test_find_fusable_matches_voice_filter_mixer():
     assert not errors and len(groups) == 1
     sink, chains = groups[0]
     assert sink is mixer and len(chains) == 6
-    assert chains[0].shape == (True, True, None, False, 0)
+    assert chains[0].shape == (True, True, None, False, 0, ())
     assert [c.voice for c in chains] == voices and chains[0].wave_id() == 2
 
 
@@ -227,7 +227,7 @@ def test_find_fusable_single_chain_and_reverb_shape():
     dac = voice | rv | Dac()
     groups, errors = fusion.find_fusable(determine_execution_order([dac]))
     assert not errors and groups[0][0] is rv
-    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10), False, 0)
+    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10), False, 0, ())
 
 
 def test_find_fusable_reports_what_it_cannot_fuse():
