@@ -142,20 +142,45 @@ __device__ __forceinline__ double wave_eval(int wave, double p, double duty_edge
     }
 }
 
+// np.mod(x, TAU) for finite |x| < 1e9 WITHOUT branches (selects only): the general
+// kernel calls it several times per sample, and lane-divergent early-outs cost far more
+// than the few operations they save.  r = |x| - k*TAU is exact for k = floor(|x|/TAU) or
+// a neighbour (see fmod_tau_nonneg); the true remainder is representable too, so the
+// repair by one exact +-TAU returns it unrounded.
+__device__ __forceinline__ double np_mod_tau_bounded(double x)
+{
+    const double a = fabs(x);
+    const double k = floor(a * kInvTau);
+    double r = __builtin_fma(-k, kTau, a);
+    r = r < 0. ? r + kTau : r;
+    r = r >= kTau ? r - kTau : r;
+    return (x < 0. && r != 0.) ? kTau - r : r;
+}
+
+template <bool BOUNDED> __device__ __forceinline__ double np_mod_tau_sel(double x)
+{
+    if constexpr (BOUNDED)
+        return np_mod_tau_bounded(x);
+    else
+        return np_mod_tau(x);
+}
+
 // The wave functions for ANY phase argument (FmOscillator evaluates them at
 // phase + intensity * modulator, oscillators.py:220; an Lfo's first phase is whatever
 // startPhase was given): math.py:9-11 wrap = np.mod(p + PI, TAU) - PI.
+// BOUNDED: the caller guarantees finite |p| < 1e9 - 4 (branch-free remainders).
+template <bool BOUNDED = false>
 __device__ __forceinline__ double wave_eval_any(int wave, double p, double duty_edge)
 {
     switch (wave) {
     case W_SINE:
         return (p >= 0. && p <= kTau) ? sin_wrapped(p) : sin(p);
     case W_SQUARE:
-        return (np_mod_tau(p + kPi) - kPi >= 0.) ? 1. : -1.;
+        return (np_mod_tau_sel<BOUNDED>(p + kPi) - kPi >= 0.) ? 1. : -1.;
     case W_SAWTOOTH:
-        return div_pi(np_mod_tau(p)) - 1.;
+        return div_pi(np_mod_tau_sel<BOUNDED>(p)) - 1.;
     case W_TRIANGLE: {
-        const double w = np_mod_tau(p + kPi) - kPi;
+        const double w = np_mod_tau_sel<BOUNDED>(p + kPi) - kPi;
         double q = div_tau(4. * w);
         q = q < 0. ? q + 4. : q;
         return 1. - fabs(q - 2.);

@@ -10,14 +10,64 @@
 //   MT_DUTY       Lfo(shape=256) | PwmOscillator.dutyCycle (oscillators.py:256-260)
 // Same mapping and data layout as voice_kernel (one lane = one voice, state in registers
 // for the whole launch, the wave's LDS tile for the mix-down); one lane's time axis is
-// serial anyway, so the running frequency sum needs no cross-lane scan.  Every sample
-// runs the exact per-sample code (no speculation): this kernel is about parity with the
-// reference's modulated paths first; envelope and filter are run-time options so that
-// only the output mode is a template parameter.
+// serial anyway, so the running frequency sum needs no cross-lane scan.  Samples are
+// handled in groups of eight (one scalar load of the time points, stage parameters in
+// registers, a Delay stage's eight reads in flight together); the arithmetic per sample
+// is the reference's.  Envelope and filter are run-time options so that only the output
+// mode is a template parameter.
 #pragma once
 #include "bank_kernels.h"
+#include <type_traits>
 
 namespace klmi {
+
+// Eight wave-function values with the dispatch OUTSIDE the sample loop: `sel` is the
+// wavefront's common wave id (scalar: one jump per group, straight-line code per case)
+// or -1, in which case every lane switches on its own `lane_wave`.
+// WRAPPED: 0 <= p < TAU (a wrapped phase); otherwise any finite phase (FM).
+template <bool WRAPPED, bool BD>
+__device__ __forceinline__ void wave_block(int sel, int lane_wave, const double (&p)[8],
+                                           double duty_edge, double (&out)[8])
+{
+    auto eval = [&](int w, double ph) {
+        if constexpr (WRAPPED)
+            return wave_eval<true>(w, ph, duty_edge);
+        else
+            return wave_eval_any<BD>(w, ph, duty_edge);
+    };
+    switch (sel) {
+    case W_SINE:
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out[j] = eval(W_SINE, p[j]);
+        break;
+    case W_SQUARE:
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out[j] = eval(W_SQUARE, p[j]);
+        break;
+    case W_SAWTOOTH:
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out[j] = eval(W_SAWTOOTH, p[j]);
+        break;
+    case W_TRIANGLE:
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out[j] = eval(W_TRIANGLE, p[j]);
+        break;
+    case W_PWM:
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out[j] = eval(W_PWM, p[j]);
+        break;
+    default:
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out[j] = eval(lane_wave, p[j]);
+        break;
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_env, int has_filter,
@@ -59,6 +109,12 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         mod_wave = bk.mod_wave[v];
         mod_phase = bk.mod_phase[v];
     }
+
+    // wave functions shared by the whole wavefront (scalar dispatch), or -1
+    const int first_wave = __builtin_amdgcn_readfirstlane(wave_id);
+    const int uniform_wave = __all(wave_id == first_wave) ? first_wave : -1;
+    const int first_mod_wave = __builtin_amdgcn_readfirstlane(mod_wave);
+    const int uniform_mod_wave = __all(mod_wave == first_mod_wave) ? first_mod_wave : -1;
 
     EnvParams ep{};
     EnvState es{};
@@ -105,10 +161,28 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         trem_phase = bk.fx_state[(size_t)(2 * trem_stage) * n + v];
         trem_z = bk.fx_state[(size_t)(2 * trem_stage + 1) * n + v];
     }
+    double trem_rate = 0., trem_depth = 0., trem_duty = 0., trem_b0 = 0., trem_a1 = 0.;
+    if (trem_stage >= 0) {
+        const double *par = bk.fx_par + (size_t)(trem_stage * kFxSlots) * n + v;
+        trem_rate = par[0], trem_depth = par[n], trem_duty = par[2 * n];
+        trem_b0 = par[3 * n], trem_a1 = par[4 * n];
+    }
     int delay_pos = 0, delay_len = 1;
+    double delay_fb = 0., delay_dw = 0.;
     if (delay_stage >= 0) {
+        const double *par = bk.fx_par + (size_t)(delay_stage * kFxSlots) * n + v;
         delay_pos = (int)bk.fx_state[(size_t)(2 * delay_stage) * n + v];
-        delay_len = (int)bk.fx_par[(size_t)(delay_stage * kFxSlots) * n + v];
+        delay_len = (int)par[0];
+        delay_fb = par[n], delay_dw = par[2 * n];
+    }
+    double fx_p0[8], fx_p1[8];   // first two parameters of every stage
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        fx_p0[s] = fx_p1[s] = 0.;
+        if (s < bk.n_fx) {
+            fx_p0[s] = bk.fx_par[(size_t)(s * kFxSlots) * n + v];
+            fx_p1[s] = bk.fx_par[(size_t)(s * kFxSlots + 1) * n + v];
+        }
     }
 
     double gl = 0., gr = 0.;
@@ -155,80 +229,184 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         const double mod_start = mod_phase;
         double running = 0.;                        // np.cumsum(frequency) within this block
         const double trem_start = trem_phase;
+        // Wave-uniform: every remainder argument of this block is finite and below 1e9 in
+        // magnitude, so the branch-free remainder applies (lane-divergent early-outs and
+        // the library fallback cost far more than the operations they save).
+        const double t_end = c_time[kBlock];
+        const bool bounded_block = __all(
+            fabs(omega) * t_end + fabs(start) < 1e9 &&
+            fabs(mod_omega) * t_end + fabs(mod_start) < 1e9 && fabs(mod_scale) < 1e8 &&
+            (kTau * kDt) * kBlock * (fabs(mod_scale) + fabs(mod_offset)) + fabs(start) < 1e9 &&
+            fabs(kTau * trem_rate) * t_end + fabs(trem_start) < 1e9);
+
+        // Eight oscillator samples (with the modulator's): per sample the reference's
+        // operations in the reference's order, but staged over the group so that every
+        // dispatch (target, wave functions) happens once per group, not once per sample.
+        auto osc_group = [&](auto bounded, const Time8 &tt, bool block_start, int sample0,
+                             double (&x)[8]) {
+            constexpr bool BD = decltype(bounded)::value;
+            double m[8], p[8];
+            if (target != MT_NONE) {   // Oscillator.sample / Lfo.sample with shape 256
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    p[j] = np_mod_tau_sel<BD>(mod_omega * tt.t[j] + mod_start);
+                wave_block<true, BD>(uniform_mod_wave, mod_wave, p, kPi, m);
+                if (target != MT_FM) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        m[j] = mod_scale * m[j] + mod_offset;
+                }
+            }
+            if (uniform_wave == W_ONE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = 1.;
+                return;
+            }
+            if (uniform_wave == W_EXTERNAL) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = bk.ext_input[(size_t)(block_base * kBlock + sample0 + j) * n + v];
+                return;
+            }
+            if (target == MT_FREQUENCY) {   // oscillators.py:61-64, sequential running sum
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool first_sample = block_start && j == 0;
+                    p[j] = first_sample ? np_mod_tau_sel<BD>(start)
+                                        : np_mod_tau_sel<BD>((kTau * kDt) * running + start);
+                    running = first_sample ? m[j] : running + m[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    p[j] = np_mod_tau_sel<BD>(omega * tt.t[j] + start);
+            }
+            if (target == MT_FM) {          // oscillators.py:220: any phase
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    p[j] = p[j] + mod_scale * m[j];
+                wave_block<false, BD>(uniform_wave, wave_id, p, duty_edge, x);
+            } else if (target == MT_DUTY) { // oscillators.py:259-260
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    x[j] = (p[j] < kTau * m[j]) ? 1. : -1.;
+            } else {
+                wave_block<true, BD>(uniform_wave, wave_id, p, duty_edge, x);
+            }
+            if (uniform_wave < 0) {         // mixed wavefront: constant and external lanes
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (wave_id == W_ONE)
+                        x[j] = 1.;
+                    else if (wave_id == W_EXTERNAL)
+                        x[j] = bk.ext_input[(size_t)(block_base * kBlock + sample0 + j) * n + v];
+                }
+            }
+        };
 
         for (int c = 0; c < NCHUNK; ++c) {
             const int s0 = b * kBlock + c * CH;
-            for (int i = 0; i < CH; ++i) {
-                const double t = c_time[c * CH + i];
-                // the modulator's sample: Oscillator.sample / Lfo.sample with shape 256
-                double m = 0.;
-                if (target != MT_NONE) {
-                    m = wave_eval_any(mod_wave, np_mod_tau(mod_omega * t + mod_start), kPi);
-                    if (target != MT_FM)
-                        m = mod_scale * m + mod_offset;
+            const Time8 *times = reinterpret_cast<const Time8 *>(c_time) + ((c * CH) >> 3);
+            // Eight samples per group: one scalar load of the time points, stage parameters
+            // from registers, and the eight delayed samples of a Delay stage fetched together
+            // (the line is at least one buffer long, so they never depend on this block's
+            // writes).  Arithmetic per sample is exactly the per-sample reference order.
+            for (int i8 = 0; i8 < CH; i8 += 8) {
+                const Time8 tt = times[i8 >> 3];
+                double x[8];
+                // -- oscillator and its modulator ---------------------------------------
+                if (bounded_block)
+                    osc_group(std::true_type{}, tt, c == 0 && i8 == 0, s0 + i8, x);
+                else
+                    osc_group(std::false_type{}, tt, c == 0 && i8 == 0, s0 + i8, x);
+                // -- envelope: speculate "no stage switch in these 8" (monotone recurrence,
+                // see voice_kernel); on a hit in any lane the exact state machine runs
+                if (has_env) {
+                    double e[8];
+                    double vv = es.value;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        vv = es.base + vv * es.coef;
+                        e[j] = vv;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(es.reached(vv)) != 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            e[j] = es.step(ep);
+                    } else {
+                        es.value = vv;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        x[j] = amp * x[j] * e[j];
                 }
-                double x;
-                if (wave_id == W_ONE) {
-                    x = 1.;
-                } else if (wave_id == W_EXTERNAL) {
-                    x = bk.ext_input[(size_t)(block_base * kBlock + s0 + i) * n + v];
-                } else if (target == MT_NONE) {
-                    x = wave_eval_any(wave_id, np_mod_tau(omega * t + start), duty_edge);
-                } else if (target == MT_FM) {
-                    const double p = np_mod_tau(omega * t + start);
-                    x = wave_eval_any(wave_id, p + mod_scale * m, duty_edge);
-                } else if (target == MT_FREQUENCY) {
-                    const double p = (c == 0 && i == 0) ? np_mod_tau(start)
-                                                        : np_mod_tau((kTau * kDt) * running + start);
-                    running = (c == 0 && i == 0) ? m : running + m;
-                    x = wave_eval_any(wave_id, p, duty_edge);
-                } else {  // MT_DUTY
-                    const double p = np_mod_tau(omega * t + start);
-                    x = (p < kTau * m) ? 1. : -1.;
-                }
-                if (has_env)
-                    x = amp * x * es.step(ep);
+                // -- stages -----------------------------------------------------------------
                 if (bk.n_fx == 0) {
-                    if (has_filter)
-                        x = bq.step(x);
+                    if (has_filter) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            x[j] = bq.step(x[j]);
+                    }
                 } else {
-                    for (int s = 0; s < bk.n_fx; ++s) {  // wave-uniform program
-                        const double *par = bk.fx_par + (size_t)(s * kFxSlots) * n + v;
-                        switch (bk.fx_kind[s]) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {   // wave-uniform program, parameters in registers
+                        const double p0 = fx_p0[s], p1 = fx_p1[s];
+                        switch (s < bk.n_fx ? (int)bk.fx_kind[s] : (int)FX_NONE) {
                         case FX_FILTER:
-                            x = bq.step(x);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                x[j] = bq.step(x[j]);
                             break;
                         case FX_GAIN:       // effects.py:67-70
-                            x = par[0] * x;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                x[j] = p0 * x[j];
                             break;
                         case FX_TRANSFORM:  // effects.py:558-561
-                            x = par[0] * x + par[n];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                x[j] = p0 * x[j] + p1;
                             break;
                         case FX_TANH:       // effects.py:480-483
-                            x = tanh(par[0] * x);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                x[j] = tanh(p0 * x[j]);
                             break;
                         case FX_OCTAVE:     // effects.py:460-462
-                            x = 2. * (x * x) - 1.;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                x[j] = 2. * (x[j] * x[j]) - 1.;
                             break;
-                        case FX_TREMOLO: {  // effects.py:117-133
-                            const double rate = par[0], depth = par[n], duty = par[2 * n];
-                            const double b0 = par[3 * n], a1 = par[4 * n];
-                            const double p = np_mod_tau(kTau * rate * t + trem_start);
-                            const double pwm = (p < kTau * duty) ? 1. : -1.;
-                            const double y = trem_z + b0 * pwm;   // lfilter([b0], [1, a1])
-                            trem_z = 0. * pwm - a1 * y;
-                            x = ((1. - depth) + depth * (.5 + .5 * y)) * x;
+                        case FX_TREMOLO:    // effects.py:117-133
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const double pa = kTau * trem_rate * tt.t[j] + trem_start;
+                                const double p = bounded_block ? np_mod_tau_bounded(pa) : np_mod_tau(pa);
+                                const double pwm = (p < kTau * trem_duty) ? 1. : -1.;
+                                const double y = trem_z + trem_b0 * pwm;   // lfilter([b0], [1, a1])
+                                trem_z = 0. * pwm - trem_a1 * y;
+                                x[j] = ((1. - trem_depth) + trem_depth * (.5 + .5 * y)) * x[j];
+                            }
                             break;
-                        }
-                        case FX_DELAY: {    // effects.py:166-174 (the blend reads the window
-                                            // after the write: wet = new + feedback * delayed)
-                            int idx = delay_pos + c * CH + i;
-                            idx = idx >= delay_len ? idx - delay_len : idx;  // length >= one buffer
-                            double *slot = bk.fx_ring + (size_t)idx * n + v;
-                            const double w = x + par[n] * *slot;
-                            if (live)
-                                *slot = w;
-                            x = (1. - par[2 * n]) * x + par[2 * n] * w;
+                        case FX_DELAY: {    // effects.py:166-174 (the blend reads the window after
+                                            // the write: wet = new + feedback * delayed)
+                            double *slot[8];
+                            double old[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                int idx = delay_pos + c * CH + i8 + j;
+                                idx = idx >= delay_len ? idx - delay_len : idx;  // length >= a buffer
+                                slot[j] = bk.fx_ring + (size_t)idx * n + v;
+                                old[j] = *slot[j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const double w = x[j] + delay_fb * old[j];
+                                if (live)
+                                    *slot[j] = w;
+                                x[j] = (1. - delay_dw) * x[j] + delay_dw * w;
+                            }
                             break;
                         }
                         default:
@@ -236,14 +414,15 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                         }
                     }
                 }
-                emit_sample<MODE>(tile, i, lane, x, gl, gr, live, out, s0, count, local);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    emit_sample<MODE>(tile, i8 + j, lane, x[j], gl, gr, live, out, s0, count, local);
             }
             flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
         }
         // next start phases: sample 256 of this block
         if (trem_stage >= 0)
-            trem_phase = np_mod_tau(kTau * bk.fx_par[(size_t)(trem_stage * kFxSlots) * n + v] *
-                                        c_time[kBlock] + trem_start);
+            trem_phase = np_mod_tau(kTau * trem_rate * c_time[kBlock] + trem_start);
         if (delay_stage >= 0)
             delay_pos = (delay_pos + kBlock) % delay_len;
         if (target != MT_NONE)
