@@ -717,6 +717,97 @@ void ko_bank_render(ko_bank *bk, int n_blocks, const ko_event *events, size_t n_
             mix[i] = mix[i] / (double)bk->n_voices;
 }
 
+/* ------------------------------------------------------------------------ */
+/* synthesizer.py:151-219: MonophonicSynthesizer / PolyphonicSynthesizer over a bank of
+ * n_instruments * poly Voice(oscillator, envelope) voices; instrument i owns voices
+ * [i*poly, (i+1)*poly).  Per buffer and instrument:
+ *   Synthesizer.update (:82-84): every note of this buffer, in order, is routed --
+ *     poly (:200-209): note-on -> next voice of the itertools.cycle (round robin),
+ *                      note-off -> every voice whose currentPitch == note.pitch
+ *                      (currentPitch as the voices' LAST update left it: the voices
+ *                      process their queues only afterwards, voices.py:55-64);
+ *     mono (:170-172): every note (already chosen by the host's NoteScheduler) -> the voice;
+ *   then only ACTIVE voices are updated (:177-179, :214-217): Voice.active
+ *   (voices.py:45-53) = pending notes or envelope stage != OFF; an inactive voice keeps
+ *   its oscillator phase.  poly: out = (sum of the active voices, in order) / poly (:219,
+ *   also for poly == 1); mono: out = the voice's samples, or silence. */
+void ko_synth_render(ko_bank *bk, int poly, int mono, int32_t *round_robin,
+                     int32_t *current_pitch, int n_blocks, const ko_note *notes, size_t n_notes,
+                     double *out, double *voices)
+{
+    const int n_inst = bk->n_voices / poly;
+    const size_t span = (size_t)n_blocks * KO_BUFFER_SIZE;
+    double buf[KO_BUFFER_SIZE];
+    size_t e = 0;
+    memset(out, 0, sizeof(double) * span * (size_t)n_inst);
+    if (voices)
+        memset(voices, 0, sizeof(double) * span * (size_t)bk->n_voices);
+    for (int inst = 0; inst < n_inst; ++inst) {
+        const int v0 = inst * poly;
+        while (e < n_notes && (int)notes[e].instrument < inst)
+            ++e;
+        for (int blk = 0; blk < n_blocks; ++blk) {
+            size_t e1 = e;
+            while (e1 < n_notes && (int)notes[e1].instrument == inst && (int)notes[e1].block == blk)
+                ++e1;
+            /* routing: target[k - e] = voice bit mask would overflow for poly > 64, so keep
+             * one (note, voice) list in delivery order */
+            const size_t cap = (e1 - e) * (size_t)poly + 1;
+            int *who = (int *)malloc(sizeof(int) * cap);
+            size_t *which = (size_t *)malloc(sizeof(size_t) * cap);
+            size_t n_del = 0;
+            for (size_t k = e; k < e1; ++k) {
+                if (mono) {
+                    who[n_del] = v0, which[n_del++] = k;
+                } else if (notes[k].velocity > 0.) { /* messages.py:49-52 Note.on */
+                    who[n_del] = v0 + round_robin[inst], which[n_del++] = k;
+                    round_robin[inst] = (round_robin[inst] + 1) % poly;
+                } else {
+                    for (int j = 0; j < poly; ++j)
+                        if (current_pitch[v0 + j] == notes[k].pitch)
+                            who[n_del] = v0 + j, which[n_del++] = k;
+                }
+            }
+            double *dst = out + (size_t)inst * span + (size_t)blk * KO_BUFFER_SIZE;
+            for (int j = 0; j < poly; ++j) {
+                const int v = v0 + j;
+                int pending = 0;
+                for (size_t d = 0; d < n_del; ++d)
+                    pending += who[d] == v;
+                if (!pending && bk->env[v].stage == KO_OFF)
+                    continue;
+                for (size_t d = 0; d < n_del; ++d) { /* voices.py:55-64 */
+                    if (who[d] != v)
+                        continue;
+                    const ko_note *nt = &notes[which[d]];
+                    const int on = nt->velocity > 0.;
+                    ko_envelope_gate(&bk->env[v], on);
+                    if (on) {
+                        bk->amplitude[v] = nt->velocity;
+                        bk->frequency[v] = nt->frequency;
+                        current_pitch[v] = nt->pitch;
+                    } else {
+                        current_pitch[v] = 0;
+                    }
+                }
+                ko_voice_block(bk, v, buf);
+                if (voices)
+                    memcpy(voices + (size_t)v * span + (size_t)blk * KO_BUFFER_SIZE, buf, sizeof(buf));
+                for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                    dst[i] += buf[i];
+            }
+            if (!mono)
+                for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                    dst[i] = dst[i] / (double)poly;
+            free(who);
+            free(which);
+            e = e1;
+        }
+        while (e < n_notes && (int)notes[e].instrument == inst)
+            ++e;
+    }
+}
+
 int ko_max_threads(void)
 {
 #ifdef _OPENMP

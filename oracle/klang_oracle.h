@@ -178,6 +178,26 @@ enum {
 void ko_bank_render(ko_bank *bank, int n_blocks, const ko_event *events, size_t n_events,
                     double *mix, double *voices, int n_threads);
 
+/* ---- synthesizer.py: note routing + activity gating over a bank ------------ */
+typedef struct {
+    uint32_t instrument;
+    uint32_t block;
+    int32_t pitch;
+    uint32_t reserved;
+    double velocity;   /* 0: note-off (messages.py:49-57) */
+    double frequency;
+} ko_note;
+
+/* MonophonicSynthesizer (mono != 0, poly == 1; notes are what the host's NoteScheduler
+ * hands to the voice) / PolyphonicSynthesizer (synthesizer.py:151-219).  bank: has_env,
+ * n_voices = instruments * poly.  notes sorted by (instrument, block), stable.
+ * round_robin [instruments], current_pitch [n_voices]: routing state, zero at start.
+ * out [instruments][n_blocks*256]; voices optional [n_voices][n_blocks*256] (zeros where a
+ * voice was not updated). */
+void ko_synth_render(ko_bank *bank, int poly, int mono, int32_t *round_robin,
+                     int32_t *current_pitch, int n_blocks, const ko_note *notes, size_t n_notes,
+                     double *out, double *voices);
+
 int ko_max_threads(void);
 
 #ifdef __cplusplus

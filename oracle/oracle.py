@@ -54,6 +54,10 @@ EVENT_DTYPE = np.dtype([('voice', '<u4'), ('block', '<u4'), ('kind', '<u4'), ('i
                         ('velocity', '<f8'), ('frequency', '<f8')])
 
 
+NOTE_DTYPE = np.dtype([('instrument', '<u4'), ('block', '<u4'), ('pitch', '<i4'),
+                       ('reserved', '<u4'), ('velocity', '<f8'), ('frequency', '<f8')])
+
+
 class Bank(C.Structure):
     _fields_ = [
         ('n_voices', C.c_int), ('has_env', C.c_int), ('has_filter', C.c_int), ('stereo', C.c_int),
@@ -129,6 +133,9 @@ def lib():
         L.ko_stereo_mixer.argtypes = [_dp, _dp, _dp, C.c_int, C.c_size_t, _dp]
         L.ko_bank_render.argtypes = [C.POINTER(Bank), C.c_int, C.POINTER(Event), C.c_size_t,
                                      _dp, _dp, C.c_int]
+        L.ko_synth_render.argtypes = [C.POINTER(Bank), C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
+                                      _dp, _dp]
         L.ko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -443,6 +450,32 @@ class OracleBank:
                              events.ctypes.data_as(C.POINTER(Event)), len(events),
                              _p(mix), _p(voices) if want_voices else None, int(n_threads))
         return mix, voices
+
+    def render_synth(self, poly, n_blocks, notes=None, mono=False, want_voices=False):
+        """PolyphonicSynthesizer / MonophonicSynthesizer routing and activity gating over
+        this bank (synthesizer.py:151-219): notes = structured array NOTE_DTYPE (any order;
+        sorted here by (instrument, block), stable).  -> out [instruments][n_blocks*256],
+        voices.  Routing state (round robin, currentPitch) persists on the object."""
+        poly = int(poly)
+        n_inst = self.n // poly
+        if not hasattr(self, 'round_robin'):
+            self.round_robin = np.zeros(n_inst, dtype=np.int32)
+            self.current_pitch = np.zeros(self.n, dtype=np.int32)
+        if notes is None:
+            notes = np.zeros(0, dtype=NOTE_DTYPE)
+        notes = np.asarray(notes, dtype=NOTE_DTYPE)
+        order = np.lexsort((notes['block'], notes['instrument']))
+        notes = np.ascontiguousarray(notes[order])
+        out = np.empty((n_inst, n_blocks * BUFFER_SIZE))
+        voices = np.empty((self.n, n_blocks * BUFFER_SIZE)) if want_voices else None
+        bank = self._struct()
+        ip = C.POINTER(C.c_int32)
+        lib().ko_synth_render(C.byref(bank), poly, int(bool(mono)),
+                              self.round_robin.ctypes.data_as(ip),
+                              self.current_pitch.ctypes.data_as(ip), int(n_blocks),
+                              notes.ctypes.data_as(C.c_void_p), len(notes), _p(out),
+                              _p(voices) if want_voices else None)
+        return out, voices
 
     def env_state(self):
         return (np.array([e.stage for e in self.env]), np.array([e.value for e in self.env]),

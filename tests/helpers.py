@@ -44,3 +44,22 @@ def library_table(hip):
         b, a = hip.butter2_lowpass(f / 22050)
         rows.append((b[0], b[1], b[2], a[1], a[2]))
     return np.array(rows), grid
+
+
+def synth_notes(oracle, rows, instrument=0):
+    """Fixture rows [block, pitch, velocity, frequency] -> oracle NOTE_DTYPE array."""
+    rows = np.asarray(rows, dtype=float).reshape(-1, 4)
+    notes = np.zeros(len(rows), dtype=oracle.NOTE_DTYPE)
+    notes['instrument'] = instrument
+    notes['block'], notes['pitch'] = rows[:, 0].astype(int), rows[:, 1].astype(int)
+    notes['velocity'], notes['frequency'] = rows[:, 2], rows[:, 3]
+    return notes
+
+
+def oracle_synth_bank(oracle, n_voices, template, wave='sawtooth'):
+    """n_voices x Voice(Oscillator(wave), ADSR(*template)), as PolyphonicSynthesizer's
+    duplicate_voice builds them (synthesizer.py:58-60, 197)."""
+    bank = oracle.OracleBank(n_voices, has_env=True, has_filter=False)
+    bank.wave[:] = oracle.WAVE_IDS[wave]
+    bank.set_envelopes(*[float(t) for t in template])
+    return bank

@@ -534,3 +534,42 @@ def test_hello_world_blocks(oracle, golden):
     osc = oracle.OscillatorState(440., 'sine')
     for b in range(4):
         eq(osc.block().astype(np.float32), g['first_blocks_f32'][b])
+
+
+# ---- synthesizers (synthesizer.py:87-219): routing + activity gating -----------------
+@pytest.mark.parametrize('key,poly', [('poly24', 24), ('poly3', 3)])
+def test_polyphonic_synthesizer_bit_exact(oracle, golden, key, poly):
+    from tests.helpers import oracle_synth_bank, synth_notes
+    g = golden('synthesizer')
+    ref = g[key + '_out']
+    bank = oracle_synth_bank(oracle, poly, g['template'])
+    notes = synth_notes(oracle, g[key + '_notes'])
+    # two calls: routing state, phases and envelopes carry over
+    cut = 7
+    first, _ = bank.render_synth(poly, cut, notes[notes['block'] < cut])
+    rest = notes[notes['block'] >= cut].copy()
+    rest['block'] -= cut
+    second, _ = bank.render_synth(poly, len(ref) - cut, rest)
+    out = np.concatenate([first[0], second[0]]).reshape(-1, B)
+    eq(out, ref)
+    state = g[key + '_state']   # currentPhase, currentPitch, amplitude, active, frequency
+    eq(bank.phase, state[:, 0])
+    eq(bank.current_pitch, state[:, 1].astype(int))
+    eq(bank.amplitude, state[:, 2])
+    eq(bank.env_state()[0] != 0, state[:, 3] != 0)
+    eq(bank.frequency, state[:, 4])
+    assert np.abs(ref).max() > .01
+
+
+@pytest.mark.parametrize('policy', ['newest', 'oldest', 'lowest', 'highest'])
+def test_monophonic_synthesizer_bit_exact(oracle, golden, policy):
+    from tests.helpers import oracle_synth_bank, synth_notes
+    g = golden('synthesizer')
+    ref = g['mono_%s_out' % policy]
+    bank = oracle_synth_bank(oracle, 1, g['template'])
+    out, _ = bank.render_synth(1, len(ref), synth_notes(oracle, g['mono_%s_handed' % policy]),
+                               mono=True)
+    eq(out.reshape(-1, B), ref)
+    state = g['mono_%s_state' % policy]
+    assert bank.phase[0] == state[0] and bank.current_pitch[0] == int(state[1])
+    assert bank.amplitude[0] == state[2]

@@ -25,7 +25,12 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 B = 256
 
 
+ONLY = set(sys.argv[1:])   # fixture names to (re)write; all when empty
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(GOLDEN, name + '.npz')
     np.savez_compressed(path, **arrays)
     print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.))
@@ -486,6 +491,71 @@ def main():
              14: [lambda: voice.input.push(Note(64, .5, frequency=329.6275569128699))]}
     fx['chain'] = run_graph(stages[-1], 30, hooks)
     save('effects', **fx)
+
+    # ---- synthesizers: synthesizer.py:87-219 -----------------
+    from klang.audio import synthesizer as SY
+    syn = {}
+
+    def E(pitch, vel=1.):
+        return Note(pitch, vel)
+
+    def run_synth(synth, script, n_blocks, voices):
+        """script: {block: [Note, ...]} -> outputs [n_blocks][256]; per-voice final state."""
+        outs = []
+        for b in range(n_blocks):
+            for note in script.get(b, []):
+                synth.input.push(note)
+            synth.update()
+            outs.append(np.array(synth.output.value, dtype=float))
+        state = np.array([[v.oscillator.currentPhase, v.currentPitch, v.amplitude,
+                           float(v.envelope.active), v.oscillator.frequency.value] for v in voices])
+        return np.array(outs), state
+
+    def notes_array(script):
+        return np.array([[b, n.pitch, n.velocity, n.frequency]
+                         for b in sorted(script) for n in script[b]])
+
+    template = lambda: A.Voice(OSC.Oscillator(wave_func=W.sawtooth), A.ADSR(.004, .02, .6, .012))
+    # 24 voices: chords, release, re-use, on+off of one pitch in one buffer, an off for a
+    # pitch nobody plays, an off for pitch 0 (matches every idle voice), late re-trigger
+    script24 = {0: [E(60), E(64, .7), E(67, .5)], 5: [E(64, 0.)], 6: [E(72, .9), E(72, 0.)],
+                7: [E(72, 0.)], 9: [E(61, 0.)], 12: [E(60, 0.), E(67, 0.)], 14: [E(0, 0.)],
+                20: [E(48, .3)], 21: [E(48, 0.), E(55, .8)], 30: [E(55, 0.)]}
+    poly = SY.PolyphonicSynthesizer(template())
+    syn['poly24_out'], syn['poly24_state'] = run_synth(poly, script24, 44, poly.voices)
+    syn['poly24_notes'] = notes_array(script24)
+    # 3 voices (same code, smaller MAX_VOICES): the round robin wraps and steals sounding voices
+    Poly3 = type('Poly3', (SY.PolyphonicSynthesizer,), {'MAX_VOICES': 3})
+    script3 = {0: [E(60), E(64)], 2: [E(67), E(71, .6)], 3: [E(60, 0.)], 4: [E(64, 0.), E(74, .8), E(76), E(77), E(79, .4)],
+               8: [E(77, 0.), E(79, 0.)], 9: [E(76, 0.)], 15: [E(50)], 16: [E(50, 0.)]}
+    poly3 = Poly3(template())
+    syn['poly3_out'], syn['poly3_state'] = run_synth(poly3, script3, 30, poly3.voices)
+    syn['poly3_notes'] = notes_array(script3)
+    # monophonic, every policy: the notes the voice receives are recorded too
+    script1 = {0: [E(60)], 2: [E(64, .8)], 4: [E(67, .6)], 6: [E(64, 0.)], 8: [E(67, 0.)],
+               10: [E(60, 0.)], 16: [E(55, .5), E(59)], 17: [E(59, 0.)], 18: [E(55, 0.)]}
+    for policy in ('newest', 'oldest', 'lowest', 'highest'):
+        mono = SY.MonophonicSynthesizer(template(), policy=policy)
+        handed = []
+        push = mono.voice.input.push
+        mono.voice.input.push = lambda note, _p=push, _h=handed: (_h.append(note), _p(note))[1]
+        outs = []
+        for b in range(30):
+            n0 = len(handed)
+            for note in script1.get(b, []):
+                mono.input.push(note)
+            mono.update()
+            outs.append(np.array(mono.output.value, dtype=float))
+            for note in handed[n0:]:
+                note_rows = syn.setdefault('mono_%s_handed' % policy, [])
+                note_rows.append([b, note.pitch, note.velocity, note.frequency])
+        syn['mono_%s_out' % policy] = np.array(outs)
+        syn['mono_%s_handed' % policy] = np.array(syn['mono_%s_handed' % policy])
+        syn['mono_%s_state' % policy] = np.array([mono.voice.oscillator.currentPhase,
+                                                  mono.voice.currentPitch, mono.voice.amplitude])
+    syn['mono_notes'] = notes_array(script1)
+    syn['template'] = np.array([.004, .02, .6, .012])
+    save('synthesizer', **syn)
 
     # ---- hello_world (config 1): Oscillator(440) | Dac, pre-normalisation ---
     osc = OSC.Oscillator(frequency=440.)
