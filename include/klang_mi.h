@@ -109,7 +109,12 @@ typedef enum {
     KLMI_F_Z0 = 36,           /* _Filter.state[0] (effects.py:305-316) */
     KLMI_F_Z1 = 37,           /* _Filter.state[1] */
     KLMI_F_LFO_PHASE = 38,    /* the cutoff Lfo's currentPhase */
-    KLMI_F_MOD_PHASE = 39     /* the modulator's currentPhase */
+    KLMI_F_MOD_PHASE = 39,    /* the modulator's currentPhase */
+    /* routing state of polyphonic banks (desc.poly_voices > 0) */
+    KLMI_F_CURRENT_PITCH = 40, /* Voice.currentPitch (voices.py:42, 62-64) */
+    KLMI_F_ROUND_ROBIN = 41    /* position of PolyphonicSynthesizer.freeVoice, the
+                                  itertools.cycle over the voices (synthesizer.py:198, 203):
+                                  per instrument, readable/settable through any of its voices */
 } klmi_field;
 
 /* Audio-rate modulation input of the voice's oscillator (one modulator per voice). */
@@ -171,6 +176,17 @@ typedef struct {
     int32_t mod_target;       /* klmi_mod_target */
     int32_t n_fx;             /* number of effect stages, 0..KLMI_MAX_FX */
     uint8_t fx[KLMI_MAX_FX];  /* klmi_fx_kind per stage */
+    /* synthesizers (klang/audio/synthesizer.py:151-219) */
+    int32_t gated;            /* 1: a voice is only updated while Voice.active (voices.py:45-53:
+                                 a note of this buffer or envelope stage != OFF), as Mono-/
+                                 PolyphonicSynthesizer.update do (synthesizer.py:177-179,
+                                 214-217); an idle voice keeps its oscillator phase.  Needs
+                                 has_env; no filter, effect stages or reverb */
+    int32_t poly_voices;      /* P > 0: the bank is n_voices / P PolyphonicSynthesizers of P
+                                 voices each (instrument i owns voices [i*P, (i+1)*P)); notes
+                                 are addressed to instruments with klmi_bank_notes and routed
+                                 on the device (synthesizer.py:200-209).  Implies gated; the
+                                 default mix divisor is P (synthesizer.py:219) */
 } klmi_chain_desc;
 
 /* Block-boundary events, the batched form of Voice.process_incoming_notes
@@ -190,6 +206,16 @@ typedef struct {
     double velocity;  /* NOTE_ON */
     double frequency; /* NOTE_ON, SET_CUTOFF, SET_FREQUENCY (Hz) */
 } klmi_event;
+
+/* A Note message (klang/messages.py:8-61) for one PolyphonicSynthesizer of a polyphonic bank. */
+typedef struct {
+    uint32_t instrument;
+    uint32_t block;    /* relative to the next klmi_bank_render call */
+    int32_t pitch;     /* 0..127 */
+    uint32_t reserved;
+    double velocity;   /* > 0: note-on, 0: note-off (messages.py:49-57) */
+    double frequency;  /* Hz */
+} klmi_note;
 
 typedef struct klmi_ctx klmi_ctx;
 typedef struct klmi_bank klmi_bank;
@@ -243,6 +269,14 @@ int klmi_bank_state_set(klmi_bank *bank, int field, int first, int count, const 
  * order, same-block events in submission order).  Events whose block lies
  * beyond the next render stay queued, re-based. */
 int klmi_bank_events(klmi_bank *bank, const klmi_event *events, size_t n);
+
+/* PolyphonicSynthesizer.process_note (synthesizer.py:200-209), batched and moved onto the
+ * device: queue notes for the instruments of a polyphonic bank (any order; applied per
+ * instrument in block order, same-block notes in submission order).  Per buffer every voice
+ * scans its instrument's notes: a note-on goes to the voice the round robin points at, a
+ * note-off to every voice whose currentPitch -- as the previous buffer left it -- equals the
+ * note's pitch. */
+int klmi_bank_notes(klmi_bank *bank, const klmi_note *notes, size_t n);
 
 /* Mixer divisor: mixer.py:46-47 divides the bus by nInputs when nInputs > 1.
  * Default is that rule on this bank's n_voices; a sharded patch sets 1.0 on

@@ -60,6 +60,16 @@ struct BankView {
     double *fx_state;          // [8][2][n]: tremolo lfo phase, zi; delay position
     double *fx_ring;           // the delay stage's rings, [fx_ring_cap][n] (slot-major)
     int fx_ring_cap;
+    // synthesizers: activity gating and device-side note routing
+    int gated;                  // voices are only updated while Voice.active
+    int poly;                   // voices per PolyphonicSynthesizer, 0: none
+    const uint32_t *nt_offset;  // notes of this render call, CSR by instrument [n/poly + 1]
+    const uint32_t *nt_block;
+    const int32_t *nt_pitch;
+    const double *nt_velocity, *nt_frequency;
+    uint32_t *nt_cursor;        // [n] state: notes of its instrument a voice has seen
+    uint32_t *round_robin;      // [n] state: the instrument's cycle position (replicated)
+    int32_t *current_pitch;     // [n] state: Voice.currentPitch
 };
 
 enum FxKind : int { FX_NONE = 0, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY };

@@ -414,6 +414,14 @@ struct klmi_bank {
     DevBuf<int32_t> ev_index;
     DevBuf<double> ev_velocity, ev_frequency;
 
+    // notes of polyphonic banks (desc.poly_voices > 0): same life cycle as the events,
+    // CSR by instrument; every voice keeps its own cursor into its instrument's notes
+    std::vector<klmi_note> pending_notes;
+    bool notes_dirty = false;
+    DevBuf<uint32_t> nt_offset, nt_block;
+    DevBuf<int32_t> nt_pitch;
+    DevBuf<double> nt_velocity, nt_frequency;
+
     // scratch
     DevBuf<float> partial, dev_mix, dev_voices_f32;
     DevBuf<double> stage;  // bus reduction, slice sums
@@ -442,7 +450,8 @@ struct klmi_bank {
 
 enum { SL_PHASE = 0, SL_ENV_VALUE, SL_Z0, SL_Z1, SL_FREQ, SL_AMP, SL_LFO_PHASE, SL_MOD_PHASE, SL_F64_COUNT,
        SL_FX_STATE = SL_F64_COUNT };  // banks with effect stages: + [8][2] slots of stage state
-enum { SL_ENV_STATE = 0, SL_COEF_INDEX, SL_EV_CURSOR, SL_U32_COUNT };
+enum { SL_ENV_STATE = 0, SL_COEF_INDEX, SL_EV_CURSOR, SL_NT_CURSOR, SL_ROUND_ROBIN, SL_CUR_PITCH,
+       SL_U32_COUNT };
 
 static BankView make_view(klmi_bank *b)
 {
@@ -486,6 +495,16 @@ static BankView make_view(klmi_bank *b)
     v.fx_state = b->desc.n_fx ? b->f64(SL_FX_STATE) : nullptr;
     v.fx_ring = b->fx_ring.p;
     v.fx_ring_cap = b->fx_ring_cap;
+    v.gated = b->desc.gated || b->desc.poly_voices > 0;
+    v.poly = b->desc.poly_voices;
+    v.nt_offset = b->nt_offset.p;
+    v.nt_block = b->nt_block.p;
+    v.nt_pitch = b->nt_pitch.p;
+    v.nt_velocity = b->nt_velocity.p;
+    v.nt_frequency = b->nt_frequency.p;
+    v.nt_cursor = b->u32(SL_NT_CURSOR);
+    v.round_robin = b->u32(SL_ROUND_ROBIN);
+    v.current_pitch = reinterpret_cast<int32_t *>(b->u32(SL_CUR_PITCH));
     return v;
 }
 
@@ -638,11 +657,20 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
             return fail(KLMI_E_ARG, "klmi_bank_create: has_filter and a KLMI_FX_FILTER stage go "
                                     "together");
     }
+    if (desc->poly_voices < 0 || (desc->poly_voices > 0 && n_voices % desc->poly_voices != 0))
+        return fail(KLMI_E_ARG, "klmi_bank_create: %d voices are not a whole number of "
+                                "instruments of poly_voices = %d", n_voices, desc->poly_voices);
+    if ((desc->gated || desc->poly_voices > 0) &&
+        (!desc->has_env || desc->has_filter || desc->n_fx || desc->has_reverb))
+        return fail(KLMI_E_ARG, "klmi_bank_create: gated / polyphonic banks are Voice(oscillator, "
+                                "envelope) chains: has_env, no filter, effect stages or reverb");
     klmi_bank *b = new klmi_bank;
     b->ctx = ctx;
     b->n = n_voices;
     b->desc = *desc;
     b->mix_divisor = n_voices > 1 ? (double)n_voices : 1.;  // mixer.py:46-47
+    if (desc->poly_voices > 0)
+        b->mix_divisor = (double)desc->poly_voices;         // synthesizer.py:219
     const size_t n = (size_t)n_voices;
     // defaults: ADSR(.1,.2,.8,1.) envelopes.py:66, overshoot 1e-3, Filter 440 Hz effects.py:353
     b->attack.assign(n, .1);
@@ -687,6 +715,13 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     chk(b->ev_index.alloc(1));
     chk(b->ev_velocity.alloc(1));
     chk(b->ev_frequency.alloc(1));
+    if (desc->poly_voices > 0) {
+        chk(b->nt_offset.alloc(n / desc->poly_voices + 1));
+        chk(b->nt_block.alloc(1));
+        chk(b->nt_pitch.alloc(1));
+        chk(b->nt_velocity.alloc(1));
+        chk(b->nt_frequency.alloc(1));
+    }
     if (e != hipSuccess) {
         delete b;
         return fail(KLMI_E_MEMORY, "klmi_bank_create: device allocation failed: %s",
@@ -700,7 +735,9 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     if (hipMemset(b->state_f64.p, 0, sizeof(double) * b->f64_slots * n) != hipSuccess ||
         hipMemset(b->state_u32.p, 0, sizeof(uint32_t) * SL_U32_COUNT * n) != hipSuccess ||
         hipMemset(b->ev_offset.p, 0, sizeof(uint32_t) * (n + 1)) != hipSuccess ||
-        hipMemset(b->wave.p, 0, sizeof(int32_t) * n) != hipSuccess)
+        hipMemset(b->wave.p, 0, sizeof(int32_t) * n) != hipSuccess ||
+        (desc->poly_voices > 0 &&
+         hipMemset(b->nt_offset.p, 0, sizeof(uint32_t) * (n / desc->poly_voices + 1)) != hipSuccess))
         step(fail(KLMI_E_DEVICE, "klmi_bank_create: memset failed"));
     step(fill_device<double>(b, b->duty.p, n, .5));           // oscillators.py:245
     step(fill_device<double>(b, b->f64(SL_FREQ), n, 440.));   // oscillators.py:121
@@ -813,6 +850,8 @@ static int state_slot(klmi_bank *b, int field, bool *is_u32)
     case KLMI_F_MOD_PHASE: return SL_MOD_PHASE;
     case KLMI_F_ENV_STAGE:
     case KLMI_F_ENV_ENABLED: *is_u32 = true; return SL_ENV_STATE;
+    case KLMI_F_CURRENT_PITCH: *is_u32 = true; return b->desc.poly_voices > 0 ? SL_CUR_PITCH : -1;
+    case KLMI_F_ROUND_ROBIN: *is_u32 = true; return b->desc.poly_voices > 0 ? SL_ROUND_ROBIN : -1;
     default: return -1;
     }
 }
@@ -972,8 +1011,12 @@ extern "C" int klmi_bank_state_get(klmi_bank *b, int field, int first, int count
     std::vector<uint32_t> raw(count);
     HIP_TRY(hipMemcpy(raw.data(), b->u32(slot) + first, sizeof(uint32_t) * count,
                       hipMemcpyDeviceToHost));
-    for (int i = 0; i < count; ++i)
-        host[i] = field == KLMI_F_ENV_STAGE ? (double)(raw[i] & 7u) : (double)((raw[i] >> 8) & 1u);
+    for (int i = 0; i < count; ++i) {
+        if (field == KLMI_F_CURRENT_PITCH || field == KLMI_F_ROUND_ROBIN)
+            host[i] = (double)raw[i];
+        else
+            host[i] = field == KLMI_F_ENV_STAGE ? (double)(raw[i] & 7u) : (double)((raw[i] >> 8) & 1u);
+    }
     return 0;
 }
 
@@ -995,8 +1038,27 @@ extern "C" int klmi_bank_state_set(klmi_bank *b, int field, int first, int count
     std::vector<uint32_t> raw(count);
     HIP_TRY(hipMemcpy(raw.data(), b->u32(slot) + first, sizeof(uint32_t) * count,
                       hipMemcpyDeviceToHost));
+    if (field == KLMI_F_ROUND_ROBIN) {
+        // one counter per instrument, replicated in its voices: set the whole instrument(s)
+        const int P = b->desc.poly_voices;
+        for (int i = 0; i < count; ++i)
+            if (!(host[i] >= 0. && host[i] < (double)P))
+                return fail(KLMI_E_ARG, "klmi_bank_state_set: round robin position %g outside "
+                                        "0..%d", host[i], P - 1);
+        for (int i = 0; i < count; ++i) {
+            const int inst = (first + i) / P;
+            std::vector<uint32_t> row(P, (uint32_t)host[i]);
+            HIP_TRY(hipMemcpy(b->u32(slot) + (size_t)inst * P, row.data(), sizeof(uint32_t) * P,
+                              hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
     for (int i = 0; i < count; ++i) {
-        if (field == KLMI_F_ENV_STAGE) {
+        if (field == KLMI_F_CURRENT_PITCH) {
+            if (!(host[i] >= 0. && host[i] < 128.))
+                return fail(KLMI_E_ARG, "Invalid pitch %g!", host[i]);  // messages.py:26-27
+            raw[i] = (uint32_t)host[i];
+        } else if (field == KLMI_F_ENV_STAGE) {
             if (!(host[i] >= 0. && host[i] <= 4.))
                 return fail(KLMI_E_ARG, "klmi_bank_state_set: bad envelope stage %g", host[i]);
             raw[i] = (raw[i] & ~7u) | (uint32_t)host[i];
@@ -1034,6 +1096,39 @@ extern "C" int klmi_bank_events(klmi_bank *b, const klmi_event *events, size_t n
     }
     if (n)
         b->events_dirty = true;
+    return 0;
+}
+
+extern "C" int klmi_bank_notes(klmi_bank *b, const klmi_note *notes, size_t n)
+{
+    if (!b)
+        return fail(KLMI_E_ARG, "klmi_bank_notes: null bank");
+    if (n && !notes)
+        return fail(KLMI_E_ARG, "klmi_bank_notes: null notes");
+    if (b->desc.poly_voices <= 0)
+        return fail(KLMI_E_STATE, "klmi_bank_notes: the bank is not polyphonic "
+                                  "(desc.poly_voices == 0); use klmi_bank_events");
+    const uint32_t n_inst = (uint32_t)(b->n / b->desc.poly_voices);
+    for (size_t i = 0; i < n; ++i) {
+        if (notes[i].instrument >= n_inst)
+            return fail(KLMI_E_ARG, "klmi_bank_notes: note %zu addresses instrument %u of %u", i,
+                        notes[i].instrument, n_inst);
+        if (notes[i].pitch < 0 || notes[i].pitch >= 128)   // messages.py:26-31
+            return fail(KLMI_E_ARG, "Invalid pitch %d!", notes[i].pitch);
+        if (!(notes[i].velocity >= 0. && notes[i].velocity <= 1.))
+            return fail(KLMI_E_ARG, "Invalid velocity %g!", notes[i].velocity);
+        if (!(notes[i].frequency >= 0.))
+            return fail(KLMI_E_ARG, "Invalid frequency %g!", notes[i].frequency);
+        if (notes[i].block > 0xFFFFFFFEu - b->block_clock)
+            return fail(KLMI_E_ARG, "klmi_bank_notes: note %zu lies too far in the future", i);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        klmi_note nt = notes[i];
+        nt.block += b->block_clock;
+        b->pending_notes.push_back(nt);
+    }
+    if (n)
+        b->notes_dirty = true;
     return 0;
 }
 
@@ -1120,6 +1215,56 @@ static int sync_events(klmi_bank *b)
     return 0;
 }
 
+// The same for the notes of a polyphonic bank, CSR by instrument.
+static int sync_notes(klmi_bank *b)
+{
+    if (!b->notes_dirty)
+        return 0;
+    std::vector<klmi_note> &q = b->pending_notes;
+    q.erase(std::remove_if(q.begin(), q.end(),
+                           [&](const klmi_note &e) { return e.block < b->block_clock; }),
+            q.end());
+    std::stable_sort(q.begin(), q.end(), [](const klmi_note &a, const klmi_note &c) {
+        return a.instrument != c.instrument ? a.instrument < c.instrument : a.block < c.block;
+    });
+    const size_t m = q.size();
+    const size_t n_inst = (size_t)(b->n / b->desc.poly_voices);
+    std::vector<uint32_t> offset(n_inst + 1, 0), block(m);
+    std::vector<int32_t> pitch(m);
+    std::vector<double> vel(m), freq(m);
+    for (size_t i = 0; i < m; ++i) {
+        offset[q[i].instrument + 1]++;
+        block[i] = q[i].block;
+        pitch[i] = q[i].pitch;
+        vel[i] = q[i].velocity;
+        freq[i] = q[i].frequency;
+    }
+    for (size_t k = 0; k < n_inst; ++k)
+        offset[k + 1] += offset[k];
+    hipStream_t st = b->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(b->nt_block.reserve(m));
+    HIP_TRY(b->nt_pitch.reserve(m));
+    HIP_TRY(b->nt_velocity.reserve(m));
+    HIP_TRY(b->nt_frequency.reserve(m));
+    HIP_TRY(hipMemcpyAsync(b->nt_offset.p, offset.data(), sizeof(uint32_t) * offset.size(),
+                           hipMemcpyHostToDevice, st));
+    if (m) {
+        HIP_TRY(hipMemcpyAsync(b->nt_block.p, block.data(), sizeof(uint32_t) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->nt_pitch.p, pitch.data(), sizeof(int32_t) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->nt_velocity.p, vel.data(), sizeof(double) * m,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->nt_frequency.p, freq.data(), sizeof(double) * m,
+                               hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemsetAsync(b->u32(SL_NT_CURSOR), 0, sizeof(uint32_t) * b->n, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->notes_dirty = false;
+    return 0;
+}
+
 template <int MODE> static size_t smem_bytes()
 {
     using TT = TileTraits<MODE>;
@@ -1181,7 +1326,7 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
                                  int n_blocks, int span_total, float *partial, void *out)
 {
     const bool plain_chain = view.n_fx == 0 || (view.n_fx == 1 && view.fx_kind[0] == FX_FILTER);
-    if (view.mod_target != MT_NONE || !plain_chain)
+    if (view.mod_target != MT_NONE || !plain_chain || view.gated)
         return launch_mod<MODE>(env, filt, st, view, first, count, block_base, clock_base, n_blocks,
                                 span_total, partial, out);
     if (env && filt)
@@ -1235,6 +1380,7 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix)
         return fail(KLMI_E_ARG, "klmi_bank_render: n_blocks must be positive, got %d", n_blocks);
     TRY(check_external(b, n_blocks));
     TRY(sync_events(b));
+    TRY(sync_notes(b));
     TRY(ensure_fx_ring(b));
     if (b->desc.has_reverb)
         return render_reverb(b, n_blocks, dev_mix);
@@ -1319,6 +1465,7 @@ static int render_preview(klmi_bank *b, int first, int count, int n_blocks, void
                                   "available; use klmi_bank_render");
     TRY(check_external(b, n_blocks));
     TRY(sync_events(b));
+    TRY(sync_notes(b));
     TRY(ensure_fx_ring(b));
     hipStream_t st = b->ctx->stream;
     const size_t n = (size_t)b->n;

@@ -196,8 +196,25 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     const uint32_t ev_end = bk.ev_offset[v + 1];
     uint32_t next_ev = (live && ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
 
+    // polyphonic banks: the voice's place in its instrument and the instrument's notes
+    const int poly = bk.poly;
+    int slot = 0, rr = 0, cur_pitch = 0;
+    uint32_t nt_i = 0, nt_end = 0, next_nt = 0xFFFFFFFFu;
+    if (poly > 0) {
+        const int inst = v / poly;
+        slot = v - inst * poly;
+        rr = (int)bk.round_robin[v];
+        cur_pitch = bk.current_pitch[v];
+        nt_i = bk.nt_offset[inst] + bk.nt_cursor[v];
+        nt_end = bk.nt_offset[inst + 1];
+        next_nt = (live && nt_i < nt_end) ? bk.nt_block[nt_i] : 0xFFFFFFFFu;
+    }
+
     for (int b = 0; b < n_blocks; ++b) {
         const uint32_t abs_block = clock_base + (uint32_t)b;
+        // Voice.active (voices.py:45-53) is asked before the notes are processed
+        const bool was_active = !has_env || es.stage != 0;
+        bool had_note = false;
         while (next_ev <= abs_block) {  // voices.py:55-64
             const uint32_t kind = bk.ev_kind[ev_i];
             if (kind == 1u) {
@@ -205,9 +222,11 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                     es.gate(ep, true);
                 amp = bk.ev_velocity[ev_i];
                 freq = bk.ev_frequency[ev_i];
+                had_note = true;
             } else if (kind == 0u) {
                 if (has_env)
                     es.gate(ep, false);
+                had_note = true;
             } else if (kind == 2u) {
                 if (has_filter) {
                     coef_row = bk.ev_index[ev_i];
@@ -220,6 +239,37 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             ++ev_i;
             next_ev = (ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
         }
+        if (poly > 0) {
+            // PolyphonicSynthesizer.process_note (synthesizer.py:200-209): every voice reads
+            // its instrument's notes of this buffer and picks out its own.  Note-offs match
+            // the pitch the voice's LAST update left (the synthesizer routes all notes before
+            // any voice processes its queue); the voice then handles its notes in order.
+            const int start_pitch = cur_pitch;
+            while (next_nt <= abs_block) {
+                const double velocity = bk.nt_velocity[nt_i];
+                const int pitch = bk.nt_pitch[nt_i];
+                if (velocity > 0.) {             // messages.py:49-52
+                    if (rr == slot) {            // next(self.freeVoice)
+                        es.gate(ep, true);
+                        amp = velocity;
+                        freq = bk.nt_frequency[nt_i];
+                        cur_pitch = pitch;
+                        had_note = true;
+                    }
+                    rr = rr + 1 == poly ? 0 : rr + 1;
+                } else if (start_pitch == pitch) {
+                    es.gate(ep, false);
+                    cur_pitch = 0;
+                    had_note = true;
+                }
+                ++nt_i;
+                next_nt = (nt_i < nt_end) ? bk.nt_block[nt_i] : 0xFFFFFFFFu;
+            }
+        }
+        // synthesizer.py:177-179, 214-217: an idle voice is not updated.  Its envelope is OFF
+        // (samples exactly 0, state unchanged); what has to stay put is the oscillator.
+        const bool run = !bk.gated || had_note || was_active;
+
         if (cutoff_lfo)
             lfo_cutoff_step(bk, v, lfo_ph, coef_row, bq);
 
@@ -433,6 +483,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             else
                 phase = np_mod_tau(omega * c_time[kBlock] + start);
         }
+        if (!run) {
+            phase = start;
+            mod_phase = mod_start;
+        }
     }
 
     if (live) {
@@ -459,6 +513,11 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         if (delay_stage >= 0)
             bk.fx_state[(size_t)(2 * delay_stage) * n + v] = (double)delay_pos;
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
+        if (poly > 0) {
+            bk.nt_cursor[v] = nt_i - bk.nt_offset[v / poly];
+            bk.round_robin[v] = (uint32_t)rr;
+            bk.current_pitch[v] = cur_pitch;
+        }
     }
 }
 

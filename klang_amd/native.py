@@ -26,6 +26,7 @@ F_LFO_FREQUENCY, F_LFO_WAVE, F_LFO_SCALE, F_LFO_OFFSET, F_MOD_FREQUENCY, F_MOD_W
     F_MOD_SCALE, F_MOD_OFFSET = range(14, 22)
 F_PHASE, F_ENV_VALUE, F_ENV_STAGE, F_ENV_ENABLED, F_Z0, F_Z1, F_LFO_PHASE, F_MOD_PHASE = \
     range(32, 40)
+F_CURRENT_PITCH, F_ROUND_ROBIN = 40, 41
 MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)   # klmi_mod_target
 # klmi_fx_kind, KLMI_F_FX / KLMI_F_FX_STATE
 FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY = range(8)
@@ -48,13 +49,16 @@ PAN_MODES = {'linear': 0, 'constant_power': 1, 'mixture': 2}
 
 EVENT_DTYPE = np.dtype([('voice', '<u4'), ('block', '<u4'), ('kind', '<u4'), ('reserved', '<u4'),
                         ('velocity', '<f8'), ('frequency', '<f8')])
+NOTE_DTYPE = np.dtype([('instrument', '<u4'), ('block', '<u4'), ('pitch', '<i4'),
+                       ('reserved', '<u4'), ('velocity', '<f8'), ('frequency', '<f8')])
 
 EXPORTS = [
     'klmi_last_error', 'klmi_version', 'klmi_ctx_create', 'klmi_ctx_destroy',
     'klmi_ctx_synchronize', 'klmi_filter_grid', 'klmi_filter_grid_index', 'klmi_butter2_lowpass',
     'klmi_envelope_coefficients', 'klmi_low_pass_coefficients', 'klmi_panning_amplitudes', 'klmi_reverb_design',
     'klmi_bank_create', 'klmi_bank_destroy', 'klmi_bank_set_params', 'klmi_bank_state_get',
-    'klmi_bank_state_set', 'klmi_bank_events', 'klmi_bank_set_mix_divisor', 'klmi_bank_set_input',
+    'klmi_bank_state_set', 'klmi_bank_events', 'klmi_bank_notes',
+    'klmi_bank_set_mix_divisor', 'klmi_bank_set_input',
     'klmi_bank_render', 'klmi_bank_render_device', 'klmi_bank_render_voices',
     'klmi_bank_render_voices_f64', 'klmi_bank_render_voices_device', 'klmi_bank_reverb_state_get',
     'klmi_bank_last_kernel_ms', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
@@ -69,7 +73,8 @@ class ChainDesc(C.Structure):
                 ('pan_law', C.c_double), ('reverb_decay', C.c_double),
                 ('reverb_pre_delay', C.c_double), ('reverb_dry_wet', C.c_double),
                 ('reverb_n_echos', C.c_int32), ('cutoff_lfo', C.c_int32),
-                ('mod_target', C.c_int32), ('n_fx', C.c_int32), ('fx', C.c_uint8 * 8)]
+                ('mod_target', C.c_int32), ('n_fx', C.c_int32), ('fx', C.c_uint8 * 8),
+                ('gated', C.c_int32), ('poly_voices', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -114,6 +119,7 @@ def load():
     L.klmi_bank_state_get.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     L.klmi_bank_state_set.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     L.klmi_bank_events.argtypes = [_vp, _vp, C.c_size_t]
+    L.klmi_bank_notes.argtypes = [_vp, _vp, C.c_size_t]
     L.klmi_bank_set_mix_divisor.argtypes = [_vp, C.c_double]
     L.klmi_bank_set_input.argtypes = [_vp, _dp, C.c_int]
     L.klmi_bank_render.argtypes = [_vp, C.c_int, _fp]
@@ -278,7 +284,7 @@ class Bank:
 
     def __init__(self, ctx, n_voices, has_env=True, has_filter=False, has_reverb=False,
                  stereo=False, pan_mode='constant_power', pan_law=None, reverb=None,
-                 cutoff_lfo=False, mod_target=MOD_NONE, effects=()):
+                 cutoff_lfo=False, mod_target=MOD_NONE, effects=(), gated=False, poly_voices=0):
         reverb = reverb or {}
         effects = [int(k) for k in effects]
         if len(effects) > MAX_FX:
@@ -288,7 +294,8 @@ class Bank:
                               float(reverb.get('decay', 1.5)), float(reverb.get('pre_delay', .03)),
                               float(reverb.get('dry_wet', .7)), int(reverb.get('n_echos', 10)),
                               int(cutoff_lfo), int(mod_target), len(effects),
-                              (C.c_uint8 * 8)(*(effects + [0] * (MAX_FX - len(effects)))))
+                              (C.c_uint8 * 8)(*(effects + [0] * (MAX_FX - len(effects)))),
+                              int(gated), int(poly_voices))
         self.effects = effects
         self.ctx = ctx
         self.n = int(n_voices)
@@ -352,6 +359,19 @@ class Bank:
         ev = np.zeros(1, dtype=EVENT_DTYPE)
         ev[0] = (voice, block, kind, 0, velocity, frequency)
         _check(load().klmi_bank_events(self._h, ev.ctypes.data_as(_vp), 1))
+
+    def notes(self, notes):
+        """Notes for the instruments of a polyphonic bank: structured array with fields
+        instrument, block, pitch, velocity, frequency (klmi_bank_notes)."""
+        nt = np.zeros(len(notes), dtype=NOTE_DTYPE)
+        for name in ('instrument', 'block', 'pitch', 'velocity', 'frequency'):
+            nt[name] = notes[name]
+        _check(load().klmi_bank_notes(self._h, nt.ctypes.data_as(_vp), len(nt)))
+
+    def note(self, instrument, block, pitch, velocity, frequency):
+        nt = np.zeros(1, dtype=NOTE_DTYPE)
+        nt[0] = (instrument, block, pitch, 0, velocity, frequency)
+        _check(load().klmi_bank_notes(self._h, nt.ctypes.data_as(_vp), 1))
 
     def set_mix_divisor(self, divisor):
         _check(load().klmi_bank_set_mix_divisor(self._h, float(divisor)))

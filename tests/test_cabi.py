@@ -28,8 +28,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(native.ChainDesc) == 80
-    assert native.EVENT_DTYPE.itemsize == 32
+    assert ctypes.sizeof(native.ChainDesc) == 88
+    assert native.EVENT_DTYPE.itemsize == 32 and native.NOTE_DTYPE.itemsize == 32
 
 
 def test_host_helpers_against_reference_fixtures(golden):
