@@ -9,10 +9,13 @@ from klang_amd.audio.effects import (Delay, Gain, OctaveDistortion, TanhDistorti
                                      Tremolo)
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.voices import Voice
+from klang_amd.audio.synthesizer import (MonophonicSynthesizer, NoteScheduler,
+                                         PolyphonicSynthesizer, Synthesizer)
 from klang_amd.audio.engine import Adc, Dac, run_audio_engine, write_wave
 
 __all__ = ['FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscillator', 'WAVE_FUNCTIONS', 'sample_phase',
            'sawtooth', 'sine', 'square', 'triangle', 'ADSR', 'AR', 'D', 'R', 'Envelope',
            'BackwardCombFilter', 'EchoFilter', 'Filter', 'ForwardCombFilter', 'Reverb', 'Mixer',
-           'StereoMixer', 'Voice', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
+           'StereoMixer', 'Voice', 'MonophonicSynthesizer', 'NoteScheduler', 'PolyphonicSynthesizer',
+           'Synthesizer', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
            'Transformer', 'Tremolo', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']

@@ -1,0 +1,143 @@
+"""Synthesizer blocks, host side (klang/audio/synthesizer.py:63-219): note
+scheduling for the monophonic synthesizer, round-robin voice allocation for the
+polyphonic one.  Under ``backend='hip'`` the graph compiler hands both to a
+gated device bank (klang_amd/fusion.py): the polyphonic routing then runs on the
+device (klmi_bank_notes), the monophonic NoteScheduler stays here because it is
+a sequential heap per instrument.
+
+Not mirrored: ``HiHat`` (white noise from NumPy's global RNG: no parity is
+possible) and ``Kick`` (its ``currentPhase`` turns into a 256-vector after the
+first buffer, synthesizer.py:282 with waves.py:61).
+"""
+import copy
+import heapq
+import itertools
+
+from klang_amd.audio.signals import MONO_SILENCE
+from klang_amd.block import Block
+from klang_amd.wiring import MessageInput
+
+__all__ = ['NoteScheduler', 'Synthesizer', 'MonophonicSynthesizer', 'PolyphonicSynthesizer']
+
+
+def duplicate_voice(voice, number):
+    """`number` copies of a voice (synthesizer.py:58-60)."""
+    return [copy.deepcopy(voice, memo=None) for _ in range(number)]
+
+
+class Synthesizer(Block):
+    """Base class: one message input, one mono output (synthesizer.py:63-84)."""
+
+    def __init__(self):
+        super().__init__(nOutputs=1)
+        self.inputs = [MessageInput(owner=self)]
+        self.output.set_value(MONO_SILENCE)
+
+    def play_note(self, *notes):
+        for note in notes:
+            self.process_note(note)
+
+    def process_note(self, note):
+        raise NotImplementedError
+
+    def update(self):
+        for note in self.input.receive():
+            self.process_note(note)
+
+
+class NoteScheduler:
+    """The sounding note-ons of a monophonic synthesizer, ordered by policy
+    (synthesizer.py:87-148): a min-heap over the reversed key; a note-off removes
+    the first entry of that pitch."""
+
+    POLICIES = ('newest', 'oldest', 'lowest', 'highest')
+
+    def __init__(self, policy='newest'):
+        assert policy in self.POLICIES
+        self.policy = policy
+        self.counter = itertools.count()
+        self.notes = []
+
+    def get_key(self, note):
+        if self.policy == 'newest':
+            key = next(self.counter)
+        elif self.policy == 'oldest':
+            key = -next(self.counter)
+        elif self.policy == 'highest':
+            key = note.pitch
+        else:
+            key = -note.pitch
+        return -key
+
+    def add_note(self, note):
+        heapq.heappush(self.notes, (self.get_key(note), note))
+
+    def remove_note(self, note):
+        for item in self.notes:
+            if item[1].pitch == note.pitch:
+                self.notes.remove(item)
+                heapq.heapify(self.notes)
+                return
+
+    def get_next_note(self, note):
+        """The note the voice has to play now, given a new note-on / note-off."""
+        if note.on:
+            self.add_note(note)
+        else:
+            self.remove_note(note)
+        if not self.notes:
+            return note
+        return self.notes[0][1]
+
+
+class MonophonicSynthesizer(Synthesizer):
+    """One voice; the scheduler decides which held note it plays
+    (synthesizer.py:151-181).  The voice is only updated while active."""
+
+    def __init__(self, voice, policy='newest'):
+        super().__init__()
+        self.voice = voice
+        self.noteScheduler = NoteScheduler(policy)
+
+    def process_note(self, note):
+        self.voice.input.push(self.noteScheduler.get_next_note(note))
+
+    def update(self):
+        super().update()
+        samples = MONO_SILENCE
+        if self.voice.active:
+            self.voice.update()
+            samples = self.voice.output.value
+        self.output.set_value(samples)
+
+
+class PolyphonicSynthesizer(Synthesizer):
+    """MAX_VOICES copies of a voice, allocated round robin; note-offs go to every
+    voice currently playing that pitch; output = sum of the active voices /
+    MAX_VOICES (synthesizer.py:184-219)."""
+
+    MAX_VOICES = 24
+
+    def __init__(self, voice):
+        super().__init__()
+        self.voices = duplicate_voice(voice, self.MAX_VOICES)
+        self.freeVoice = itertools.cycle(self.voices)
+        self.allocated = 0   # note-ons handed out so far (the cycle's position)
+
+    def process_note(self, note):
+        if note.on:
+            next(self.freeVoice).input.push(note)
+            self.allocated += 1
+        else:
+            for voice in self.voices:
+                if voice.currentPitch == note.pitch:
+                    voice.input.push(note)
+
+    def update(self):
+        super().update()
+        samples = MONO_SILENCE.copy()
+        for voice in self.voices:
+            if voice.active:
+                voice.update()
+                samples += voice.output.value
+        self.output.set_value(samples / self.MAX_VOICES)

@@ -16,6 +16,9 @@ with, optionally, one modulation source per voice:
 
 is replaced, together with the chain blocks, by one ``GpuVoiceBank`` block that
 owns a device-resident ``klang_amd.native.Bank`` (one voice per mixer input).
+``PolyphonicSynthesizer`` / ``MonophonicSynthesizer`` blocks, alone
+or as the inputs of one mixer, become *gated* banks: one voice per synthesizer voice,
+updated only while active; the polyphonic note routing runs on the device.
 Chains that end anywhere else (``Oscillator(440.) | Dac()``) become one-voice
 banks.  Per buffer the bank block drains the voices' note queues into
 block-boundary events (voices.py:55-64), renders, and publishes the mix on the
@@ -36,6 +39,8 @@ from klang_amd.audio.filtering import BackwardCombFilter, Filter, Reverb
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.signals import (BUFFER_SIZE, SCALAR, FmOscillator, Lfo, Oscillator, Phasor,
                                       PwmOscillator, WAVE_IDS)
+from klang_amd.audio.synthesizer import (MonophonicSynthesizer, PolyphonicSynthesizer,
+                                         Synthesizer)
 from klang_amd.audio.voices import Voice
 from klang_amd.block import Block
 from klang_amd.composite import Composite
@@ -45,7 +50,7 @@ from klang_amd.tempo import compute_rate
 EFFECT_KINDS = {Filter: native.FX_FILTER, Gain: native.FX_GAIN, Transformer: native.FX_TRANSFORM,
                 TanhDistortion: native.FX_TANH, OctaveDistortion: native.FX_OCTAVE,
                 Tremolo: native.FX_TREMOLO, Delay: native.FX_DELAY}
-HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer) + tuple(
+HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer, Synthesizer) + tuple(
     t for t in EFFECT_KINDS if t is not Filter)
 
 
@@ -184,9 +189,13 @@ class GpuVoiceBank(Block):
     """A fused set of chains evaluated by one device bank.  `sink` is the block
     whose output carries the result (the mixer, or the chain end itself)."""
 
-    def __init__(self, chains, sink, ctx=None):
+    def __init__(self, chains, sink, ctx=None, synths=()):
         super().__init__()
         self.chains, self.sink = chains, sink
+        # synthesizers whose voices the chains are, in voice order (synthesizer.py:151-219)
+        self.synths = list(synths)
+        self.poly = (self.synths[0].MAX_VOICES
+                     if self.synths and isinstance(self.synths[0], PolyphonicSynthesizer) else 0)
         self.ctx = ctx or native.default_context()
         has_env, has_filter, reverb, cutoff_lfo, mod_target, program = chains[0].shape
         self.cutoff_lfo, self.mod_target, self.program = cutoff_lfo, mod_target, program
@@ -199,7 +208,12 @@ class GpuVoiceBank(Block):
             self.ctx, len(chains), has_env=has_env, has_filter=has_filter,
             has_reverb=reverb is not None, stereo=self.stereo,
             reverb=dict(zip(('decay', 'pre_delay', 'dry_wet', 'n_echos'), reverb)) if reverb else None,
-            cutoff_lfo=cutoff_lfo, mod_target=mod_target, effects=program, **kw)
+            cutoff_lfo=cutoff_lfo, mod_target=mod_target, effects=program,
+            gated=bool(self.synths), poly_voices=self.poly, **kw)
+        if self.poly and self.is_mixer and len(self.synths) > 1:
+            # mean over the synthesizers of (sum of voices / MAX_VOICES): mixer.py:46-47 after
+            # synthesizer.py:219
+            self.bank.set_mix_divisor(float(self.poly * len(self.synths)))
         self.lookahead = 1      # blocks rendered per device call (set by run_klang)
         self.remaining = None   # buffers still to be delivered, when the caller knows (offline
                                 # bounce): rendering ahead never runs past the end of the piece
@@ -251,11 +265,21 @@ class GpuVoiceBank(Block):
         for s in range(len(self.program)):
             self._upload_stage(s, force=True)
         if self.is_mixer:
-            bank.set(F.F_GAIN, [float(g) for g in self.sink.gains])
+            bank.set(F.F_GAIN, self._per_voice(self.sink.gains))
             if self.stereo:
-                bank.set(F.F_PAN, [float(p) for p in self.sink.pannings])
+                bank.set(F.F_PAN, self._per_voice(self.sink.pannings))
             self._gains = list(self.sink.gains)
             self._pans = list(getattr(self.sink, 'pannings', []))
+        if self.poly:
+            P = self.poly
+            bank.set_state(F.F_CURRENT_PITCH, [float(c.voice.currentPitch) for c in ch])
+            for i, syn in enumerate(self.synths):
+                bank.set_state(F.F_ROUND_ROBIN, [float(syn.allocated % P)], first=i * P)
+
+    def _per_voice(self, per_input):
+        """A mixer's per-input values (gains, pannings), one per bank voice."""
+        rep = self.poly or 1
+        return [float(x) for x in per_input for _ in range(rep)]
 
     @staticmethod
     def _stage_params(stage):
@@ -296,6 +320,16 @@ class GpuVoiceBank(Block):
         """Voice.process_incoming_notes (voices.py:55-64) for every voice, plus
         parameter edits made on the host blocks since the last buffer."""
         F, bank = native, self.bank
+        for i, syn in enumerate(self.synths):
+            for note in syn.input.receive():            # Synthesizer.update, synthesizer.py:82-84
+                if self.poly:
+                    # routed on the device; the host block only keeps its cycle in step
+                    bank.note(i, 0, note.pitch, note.velocity, note.frequency)
+                    if note.on:
+                        next(syn.freeVoice)
+                        syn.allocated += 1
+                else:
+                    syn.process_note(note)              # NoteScheduler -> voice.input
         for i, c in enumerate(self.chains):
             if c.voice is not None:
                 for note in c.voice.input.receive():
@@ -319,15 +353,16 @@ class GpuVoiceBank(Block):
         if self.is_mixer:
             if list(self.sink.gains) != self._gains:
                 self._gains = list(self.sink.gains)
-                bank.set(F.F_GAIN, [float(g) for g in self._gains])
+                bank.set(F.F_GAIN, self._per_voice(self._gains))
             if self.stereo and list(self.sink.pannings) != self._pans:
                 self._pans = list(self.sink.pannings)
-                bank.set(F.F_PAN, [float(p) for p in self._pans])
+                bank.set(F.F_PAN, self._per_voice(self._pans))
 
     @property
     def pending_messages(self):
-        return any(c.voice is not None and (c.voice.input.queue or c.envelope.input.queue)
-                   for c in self.chains)
+        return (any(syn.input.queue for syn in self.synths)
+                or any(c.voice is not None and (c.voice.input.queue or c.envelope.input.queue)
+                       for c in self.chains))
 
     def update(self):
         if self._ready and self.pending_messages:
@@ -373,12 +408,42 @@ class GpuVoiceBank(Block):
             for i, c in enumerate(self.chains):
                 c.envelope.value, c.envelope.stage = float(value[i]), int(stage[i])
                 c.envelope.enabled = bool(enabled[i])
+        if self.poly:   # what the device-side routing decided
+            pitch, amp = bank.get_state(F.F_CURRENT_PITCH), bank.get_state(F.F_AMPLITUDE)
+            freq = bank.get_state(F.F_FREQUENCY)
+            for i, c in enumerate(self.chains):
+                c.voice.currentPitch, c.voice.amplitude = int(pitch[i]), float(amp[i])
+                c.oscillator.frequency.set_value(float(freq[i]))
 
     def close(self):
         self.bank.close()
 
     def __str__(self):
         return 'GpuVoiceBank(%d voices -> %s)' % (len(self.chains), type(self.sink).__name__)
+
+
+def synth_chains(synths):
+    """One Chain per voice of the synthesizers (all of one kind and one shape)."""
+    kinds = {type(s) for s in synths}
+    if len(kinds) != 1 or not issubclass(next(iter(kinds)),
+                                         (MonophonicSynthesizer, PolyphonicSynthesizer)):
+        raise NotFusable('synthesizers of different kinds (%s) in one bank'
+                         % ', '.join(sorted(k.__name__ for k in kinds)))
+    if len({getattr(s, 'MAX_VOICES', 1) for s in synths}) != 1:
+        raise NotFusable('polyphonic synthesizers with different MAX_VOICES in one bank')
+    chains = []
+    for syn in synths:
+        for voice in (syn.voices if isinstance(syn, PolyphonicSynthesizer) else [syn.voice]):
+            if not isinstance(voice, Voice):
+                raise NotFusable('%s: its voice is a %s, not a Voice' % (syn, type(voice).__name__))
+            if any(o.connected for o in voice.outputs):
+                raise NotFusable('%s: a voice output is patched elsewhere' % syn)
+            chains.append(Chain(voice))
+    if len({c.shape for c in chains}) != 1:
+        raise NotFusable('synthesizer voices of different shapes')
+    if chains[0].filter or chains[0].stages or chains[0].reverb:
+        raise NotFusable('synthesizer voices are plain Voice(oscillator, envelope) chains')
+    return chains
 
 
 def _flat(order):
@@ -389,25 +454,40 @@ def _flat(order):
 
 
 def find_fusable(exec_order):
-    """-> (groups, errors): groups = [(sink, [Chain, ...])] for every mixer whose
+    """-> (groups, errors): groups = [(sink, [Chain, ...], synthesizers)] for every mixer whose
     inputs are uniform chains and for every other chain end; errors = reasons
     for hot-path blocks that stay outside."""
     groups, errors, claimed = [], [], set()
     for blk in exec_order:
         if isinstance(blk, Mixer) and blk.nInputs > 0:
             try:
-                chains = []
+                chains, sources = [], []
                 for inp in blk.inputs:
                     src = inp.incomingConnection
                     if src is None or src.owner is None:
                         raise NotFusable('%s has an unconnected input' % blk)
                     if len(src.outgoingConnections) != 1:
                         raise NotFusable('%s feeds more than one input' % src.owner)
-                    chains.append(Chain(src.owner))
+                    sources.append(src.owner)
+                if sources and all(isinstance(s, Synthesizer) for s in sources):
+                    chains = synth_chains(sources)       # a mixer of synthesizers: one bank
+                    groups.append((blk, chains, sources))
+                    claimed.update(sources)
+                    claimed.add(blk)
+                    continue
+                chains = [Chain(s) for s in sources]
                 if len({c.shape for c in chains}) != 1:
                     raise NotFusable('%s mixes chains of different shapes' % blk)
-                groups.append((blk, chains))
+                groups.append((blk, chains, ()))
                 claimed.update(b for c in chains for b in c.blocks)
+                claimed.add(blk)
+            except NotFusable as err:
+                errors.append(str(err))
+    # synthesizers that feed something other than a fused mixer: a bank each
+    for blk in exec_order:
+        if isinstance(blk, Synthesizer) and blk not in claimed:
+            try:
+                groups.append((blk, synth_chains([blk]), [blk]))
                 claimed.add(blk)
             except NotFusable as err:
                 errors.append(str(err))
@@ -422,7 +502,7 @@ def find_fusable(exec_order):
             continue   # not the end of its chain
         try:
             chain = Chain(blk)
-            groups.append((blk, [chain]))
+            groups.append((blk, [chain], ()))
             claimed.update(chain.blocks)
         except NotFusable as err:
             errors.append(str(err))
@@ -434,10 +514,11 @@ def compile_order(exec_order, ctx=None, strict=True):
     strict=True every hot-path block must end up fused (KlangError otherwise)."""
     groups, errors = find_fusable(exec_order)
     fused_blocks, banks_at = set(), {}
-    for sink, chains in groups:
-        bank = GpuVoiceBank(chains, sink, ctx)
+    for sink, chains, synths in groups:
+        bank = GpuVoiceBank(chains, sink, ctx, synths)
         for c in chains:
             fused_blocks.update(c.blocks)
+        fused_blocks.update(synths)
         fused_blocks.add(sink)
         banks_at[sink] = bank
     new_order = []

@@ -260,3 +260,79 @@ def test_host_side_gain_edits_reach_the_device(hip):
         out.append(np.array(gain.output.value))
     banks[0].close()
     assert abs(np.abs(out[2]).max() - 1.) < 1e-2 and abs(np.abs(out[4]).max() - .25) < 1e-2
+
+
+# ---- synthesizers -------------------------------------------------------
+def _synth_template(g):
+    return Voice(Oscillator(wave_func=sawtooth), ADSR(*[float(x) for x in g['template']]))
+
+
+def _play_compiled(order, inputs, rows_per_input, n_blocks, out_block):
+    by_block = {}
+    for blk_in, rows in zip(inputs, rows_per_input):
+        for blk, pitch, velocity, frequency in rows:
+            by_block.setdefault(int(blk), []).append((blk_in, Note(int(pitch), velocity, frequency)))
+    out = []
+    for b in range(n_blocks):
+        for blk_in, note in by_block.get(b, ()):
+            blk_in.input.push(note)
+        for blk in order:
+            blk.update()
+        out.append(np.array(out_block.output.value, dtype=float))
+    return np.array(out)
+
+
+def test_polyphonic_synthesizer_through_the_api(hip, golden):
+    from klang_amd.audio import PolyphonicSynthesizer
+    g = golden('synthesizer')
+    poly = PolyphonicSynthesizer(_synth_template(g))
+    dac = poly | Dac()
+    order, banks = fusion.compile_order(determine_execution_order([dac]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac'] and banks[0].poly == 24
+    got = _play_compiled(order, [poly], [g['poly24_notes']], len(g['poly24_out']), poly)
+    assert np.abs(got - g['poly24_out']).max() <= 1e-6
+    banks[0].sync_host_blocks()
+    state = g['poly24_state']
+    assert [v.currentPitch for v in poly.voices] == list(state[:, 1].astype(int))
+    assert [v.oscillator.currentPhase for v in poly.voices] == list(state[:, 0])
+    assert [v.amplitude for v in poly.voices] == list(state[:, 2])
+    assert poly.allocated == int((g['poly24_notes'][:, 2] > 0).sum())
+    banks[0].close()
+
+
+def test_mixer_of_synthesizers_is_one_bank(hip, golden):
+    """Two 3-voice synthesizers and gains into one Mixer: one device bank of 6 voices;
+    mixer.py:41-49 over synthesizer.py:211-219."""
+    from klang_amd.audio import PolyphonicSynthesizer
+    g = golden('synthesizer')
+    Poly3 = type('Poly3', (PolyphonicSynthesizer,), {'MAX_VOICES': 3})
+    a, b = Poly3(_synth_template(g)), Poly3(_synth_template(g))
+    mixer = Mixer()
+    mixer += a
+    mixer += b
+    mixer.gains[:] = [.7, 1.3]
+    order, banks = fusion.compile_order(determine_execution_order([mixer | Dac()]))
+    assert [type(x).__name__ for x in order] == ['GpuVoiceBank', 'Dac'] and len(banks) == 1
+    n = len(g['poly3_out'])
+    shifted = g['poly3_notes'].copy()
+    shifted[:, 0] += 3                                   # the second one starts 3 buffers later
+    got = _play_compiled(order, [a, b], [g['poly3_notes'], shifted], n, mixer)
+    late = np.concatenate([np.zeros((3, B)), g['poly3_out']])[:n]
+    want = (.7 * g['poly3_out'] + 1.3 * late) / 2
+    assert np.abs(got - want).max() <= 1e-6 and np.abs(want).max() > .05
+    banks[0].close()
+
+
+@pytest.mark.parametrize('policy', ['newest', 'lowest'])
+def test_monophonic_synthesizer_through_the_api(hip, golden, policy):
+    from klang_amd.audio import MonophonicSynthesizer
+    g = golden('synthesizer')
+    mono = MonophonicSynthesizer(_synth_template(g), policy=policy)
+    order, banks = fusion.compile_order(determine_execution_order([mono | Dac()]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac']
+    want = g['mono_%s_out' % policy]
+    got = _play_compiled(order, [mono], [g['mono_notes']], len(want), mono)
+    assert np.abs(got - want).max() <= 1e-6
+    banks[0].sync_host_blocks()
+    assert mono.voice.oscillator.currentPhase == g['mono_%s_state' % policy][0]
+    banks[0].close()

@@ -211,7 +211,7 @@ def test_find_fusable_matches_voice_filter_mixer():
     order = determine_execution_order([dac])
     groups, errors = fusion.find_fusable(order)
     assert not errors and len(groups) == 1
-    sink, chains = groups[0]
+    sink, chains, _ = groups[0]
     assert sink is mixer and len(chains) == 6
     assert chains[0].shape == (True, True, None, False, 0, ())
     assert [c.voice for c in chains] == voices and chains[0].wave_id() == 2
@@ -221,7 +221,7 @@ def test_find_fusable_single_chain_and_reverb_shape():
     osc = Oscillator(440.)
     dac = osc | Dac()
     groups, errors = fusion.find_fusable(determine_execution_order([dac]))
-    assert not errors and [(s, len(c)) for s, c in groups] == [(osc, 1)]
+    assert not errors and [(s, len(c)) for s, c, _ in groups] == [(osc, 1)]
     voice = Voice(Oscillator(), AR(.01, 1.))
     rv = Reverb(decay=3., dryWet=.7)
     dac = voice | rv | Dac()
@@ -285,3 +285,110 @@ def test_effect_blocks_match_reference_fixtures(golden):
     _run_effect(lambda: Delay(time=.0437, feedback=.9, drywet=.5), 40, 'delay_long', golden)
     with pytest.raises(ValueError):
         Delay(time=2.5)
+
+
+# ---- synthesizers (synthesizer.py:87-219) ------------------------------------------
+def _notes(*pitches, velocity=1.):
+    from klang_amd.messages import Note
+    return [Note(pitch=p, velocity=velocity) for p in pitches]
+
+
+def test_note_scheduler_known_answers():
+    """The reference's own KATs (tests/test_audio_synthesizer.py:24-74), restated."""
+    from klang_amd.audio import NoteScheduler
+    C_ON, E_ON, G_ON = _notes(60, 64, 67)
+    C_OFF, E_OFF, G_OFF = _notes(60, 64, 67, velocity=0.)
+    rising = [C_ON, E_ON, G_ON, C_OFF, E_OFF, G_OFF]
+    rise_fall = [C_ON, E_ON, G_ON, G_OFF, E_OFF, C_OFF]
+    falling = [G_ON, E_ON, C_ON, G_OFF, E_OFF, C_OFF]
+    fall_rise = [G_ON, E_ON, C_ON, C_OFF, E_OFF, G_OFF]
+    expected = {
+        'newest': ([C_ON, E_ON, G_ON, G_ON, G_ON, G_OFF], [C_ON, E_ON, G_ON, E_ON, C_ON, C_OFF],
+                   [G_ON, E_ON, C_ON, C_ON, C_ON, C_OFF], [G_ON, E_ON, C_ON, E_ON, G_ON, G_OFF]),
+        'oldest': ([C_ON, C_ON, C_ON, E_ON, G_ON, G_OFF], [C_ON, C_ON, C_ON, C_ON, C_ON, C_OFF],
+                   [G_ON, G_ON, G_ON, E_ON, C_ON, C_OFF], [G_ON, G_ON, G_ON, G_ON, G_ON, G_OFF]),
+        'lowest': ([C_ON, C_ON, C_ON, E_ON, G_ON, G_OFF], [C_ON, C_ON, C_ON, C_ON, C_ON, C_OFF],
+                   [G_ON, E_ON, C_ON, C_ON, C_ON, C_OFF], [G_ON, E_ON, C_ON, E_ON, G_ON, G_OFF]),
+        'highest': ([C_ON, E_ON, G_ON, G_ON, G_ON, G_OFF], [C_ON, E_ON, G_ON, E_ON, C_ON, C_OFF],
+                    [G_ON, G_ON, G_ON, E_ON, C_ON, C_OFF], [G_ON, G_ON, G_ON, G_ON, G_ON, G_OFF]),
+    }
+    for policy, wants in expected.items():
+        sched = NoteScheduler(policy=policy)
+        for seq, want in zip((rising, rise_fall, falling, fall_rise), wants):
+            assert [sched.get_next_note(n) for n in seq] == want, policy
+    sched = NoteScheduler()
+    assert sched.get_next_note(C_ON) == C_ON and sched.get_next_note(C_OFF) == C_OFF
+
+
+def _play(synth, rows, n_blocks):
+    from klang_amd.messages import Note
+    by_block = {}
+    for blk, pitch, velocity, frequency in rows:
+        by_block.setdefault(int(blk), []).append(Note(int(pitch), velocity, frequency))
+    out = []
+    for b in range(n_blocks):
+        for note in by_block.get(b, ()):
+            synth.input.push(note)
+        synth.update()
+        out.append(np.array(synth.output.value, dtype=float))
+    return np.array(out)
+
+
+def _template(g):
+    from klang_amd.audio import ADSR, Oscillator, Voice, sawtooth
+    return Voice(Oscillator(wave_func=sawtooth), ADSR(*[float(x) for x in g['template']]))
+
+
+def test_host_synthesizers_vs_golden(golden):
+    """The host blocks (NumPy evaluation, backend='host') against the real reference."""
+    from klang_amd.audio import MonophonicSynthesizer, PolyphonicSynthesizer
+    from klang_amd.messages import Note
+    g = golden('synthesizer')
+    # Note's default frequency is the reference's equal temperament
+    for blk, pitch, velocity, frequency in g['poly24_notes']:
+        assert Note(int(pitch), velocity).frequency == frequency
+    poly = PolyphonicSynthesizer(_template(g))
+    got = _play(poly, g['poly24_notes'], len(g['poly24_out']))
+    np.testing.assert_allclose(got, g['poly24_out'], rtol=0, atol=1e-15)
+    assert [v.currentPitch for v in poly.voices] == list(g['poly24_state'][:, 1].astype(int))
+    Poly3 = type('Poly3', (PolyphonicSynthesizer,), {'MAX_VOICES': 3})
+    got = _play(Poly3(_template(g)), g['poly3_notes'], len(g['poly3_out']))
+    np.testing.assert_allclose(got, g['poly3_out'], rtol=0, atol=1e-15)
+    for policy in ('newest', 'oldest', 'lowest', 'highest'):
+        mono = MonophonicSynthesizer(_template(g), policy=policy)
+        handed = []
+        push = mono.voice.input.push
+        mono.voice.input.push = lambda note, _p=push: (handed.append(note), _p(note))[1]
+        got = _play(mono, g['mono_notes'], len(g['mono_%s_out' % policy]))
+        np.testing.assert_allclose(got, g['mono_%s_out' % policy], rtol=0, atol=1e-15)
+        want = g['mono_%s_handed' % policy]
+        assert [(n.pitch, n.velocity) for n in handed] == [(int(r[1]), r[2]) for r in want]
+
+
+def test_find_fusable_synthesizers():
+    from klang_amd import fusion
+    from klang_amd.audio import (ADSR, Dac, Filter, Mixer, MonophonicSynthesizer, Oscillator,
+                                 PolyphonicSynthesizer, Voice)
+    from klang_amd.schedule import determine_execution_order
+    make = lambda: Voice(Oscillator(), ADSR())
+    poly = PolyphonicSynthesizer(make())
+    groups, errors = fusion.find_fusable(determine_execution_order([poly | Dac()]))
+    assert not errors and len(groups) == 1
+    sink, chains, synths = groups[0]
+    assert sink is poly and len(chains) == 24 and synths == [poly]
+    # a mixer of synthesizers is ONE bank; kinds must not be mixed
+    mixer = Mixer()
+    a, b = PolyphonicSynthesizer(make()), PolyphonicSynthesizer(make())
+    mixer += a
+    mixer += b
+    groups, errors = fusion.find_fusable(determine_execution_order([mixer | Dac()]))
+    assert not errors and len(groups) == 1 and len(groups[0][1]) == 48 and groups[0][2] == [a, b]
+    mixer = Mixer()
+    mixer += PolyphonicSynthesizer(make())
+    mixer += MonophonicSynthesizer(make())
+    groups, errors = fusion.find_fusable(determine_execution_order([mixer | Dac()]))
+    assert any('different kinds' in e for e in errors)
+    # effects after a synthesizer work on the summed signal: not a per-voice chain
+    syn = PolyphonicSynthesizer(make())
+    groups, errors = fusion.find_fusable(determine_execution_order([syn | Filter() | Dac()]))
+    assert any('not an oscillator' in e for e in errors)
