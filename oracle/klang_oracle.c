@@ -808,6 +808,60 @@ void ko_synth_render(ko_bank *bk, int poly, int mono, int32_t *round_robin,
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* The output side of an offline bounce: klanggeber.py:81-97 pack_signals (float64 ->
+ * float32, interleaved), :205-209, 243-249 fade-out (np.interp over [fadeOutStart,
+ * duration] at playTime + T, only for buffers with playTime >= fadeOutStart; playTime
+ * is the running float64 sum of INTERVAL), then wavfile.py:54-63 write_wave with
+ * math.py:14-21 normalize_values: float32 audio / its float32 peak * 32767 (float32
+ * arithmetic, NumPy keeps the array's dtype against Python scalars), truncated to int16.
+ * bus: [n_blocks][channels][256] float32 (what the Dac's inputs hold, rounded once).
+ * frames: [n_blocks*256][channels] float32.  pcm may be NULL.  Returns the peak
+ * (0: silence -- the reference raises ValueError, pcm is then left untouched). */
+float ko_bounce(const float *bus, int n_blocks, int channels, double duration, double fadeout,
+                float *frames, int16_t *pcm)
+{
+    const double dt = 1. / KO_SAMPLING_RATE;
+    const double fade_start = duration - fadeout;
+    const double slope = (0. - 1.) / (duration - fade_start); /* numpy arr_interp */
+    double play_time = 0.;
+    for (int b = 0; b < n_blocks; ++b) {
+        for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+            double env = 1.;
+            const int fading = play_time >= fade_start;
+            if (fading) {
+                const double x = play_time + dt * (double)i; /* helpers.py:30 T */
+                if (x > duration)
+                    env = 0.; /* right */
+                else if (x < fade_start)
+                    env = 1.; /* left */
+                else if (x == duration)
+                    env = 0.;
+                else
+                    env = slope * (x - fade_start) + 1.;
+            }
+            for (int c = 0; c < channels; ++c) {
+                float v = bus[((size_t)b * channels + c) * KO_BUFFER_SIZE + i];
+                if (fading)
+                    v = (float)((double)v * env); /* float32 array *= float64 array */
+                frames[((size_t)b * KO_BUFFER_SIZE + i) * channels + c] = v;
+            }
+        }
+        play_time += KO_INTERVAL;
+    }
+    const size_t total = (size_t)n_blocks * KO_BUFFER_SIZE * channels;
+    float peak = 0.f;
+    for (size_t k = 0; k < total; ++k) {
+        const float a = fabsf(frames[k]);
+        if (a > peak)
+            peak = a;
+    }
+    if (pcm && peak != 0.f)
+        for (size_t k = 0; k < total; ++k)
+            pcm[k] = (int16_t)(frames[k] / peak * 32767.f);
+    return peak;
+}
+
 int ko_max_threads(void)
 {
 #ifdef _OPENMP

@@ -198,6 +198,13 @@ void ko_synth_render(ko_bank *bank, int poly, int mono, int32_t *round_robin,
                      int32_t *current_pitch, int n_blocks, const ko_note *notes, size_t n_notes,
                      double *out, double *voices);
 
+/* ---- klanggeber.py / wavfile.py: output side of an offline bounce --------- */
+/* pack_signals + fade-out + peak-normalised int16 (klanggeber.py:81-97, 205-249,
+ * wavfile.py:54-63, math.py:14-21).  bus [n_blocks][channels][256] float32 ->
+ * frames [n_blocks*256][channels] float32, pcm (optional) int16; returns the peak. */
+float ko_bounce(const float *bus, int n_blocks, int channels, double duration, double fadeout,
+                float *frames, int16_t *pcm);
+
 int ko_max_threads(void);
 
 #ifdef __cplusplus

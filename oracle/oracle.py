@@ -136,6 +136,9 @@ def lib():
         L.ko_synth_render.argtypes = [C.POINTER(Bank), C.c_int, C.c_int, C.POINTER(C.c_int32),
                                       C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.c_size_t,
                                       _dp, _dp]
+        L.ko_bounce.restype = C.c_float
+        L.ko_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                C.c_void_p, C.c_void_p]
         L.ko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -480,6 +483,19 @@ class OracleBank:
     def env_state(self):
         return (np.array([e.stage for e in self.env]), np.array([e.value for e in self.env]),
                 np.array([e.enabled for e in self.env]))
+
+
+def bounce(bus, duration, fadeout=0., want_pcm=True):
+    """Output side of an offline bounce (klanggeber.py:81-97, 205-249, wavfile.py:54-63):
+    bus [n_blocks][channels][256] -> (frames float32 [n_blocks*256][channels], int16 pcm or
+    None, peak)."""
+    bus = np.ascontiguousarray(bus, dtype=np.float32)
+    n_blocks, channels, _ = bus.shape
+    frames = np.empty((n_blocks * BUFFER_SIZE, channels), dtype=np.float32)
+    pcm = np.zeros((n_blocks * BUFFER_SIZE, channels), dtype=np.int16) if want_pcm else None
+    peak = lib().ko_bounce(bus.ctypes.data, n_blocks, channels, float(duration), float(fadeout),
+                           frames.ctypes.data, pcm.ctypes.data if want_pcm else None)
+    return frames, pcm, float(peak)
 
 
 def max_threads():

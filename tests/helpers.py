@@ -63,3 +63,10 @@ def oracle_synth_bank(oracle, n_voices, template, wave='sawtooth'):
     bank.wave[:] = oracle.WAVE_IDS[wave]
     bank.set_envelopes(*[float(t) for t in template])
     return bank
+
+
+def bounce_signals(name, n_blocks, channels):
+    """The seeded float64 buffers tools/gen_golden.py placed on the reference's Dac for the
+    'bounce' fixtures (same recipe; the fixture stores a checksum)."""
+    r = np.random.default_rng(len(name))
+    return (2. * r.random((n_blocks, channels, B)) - 1.) * np.linspace(.2, 1.3, n_blocks)[:, None, None]

@@ -573,3 +573,23 @@ def test_monophonic_synthesizer_bit_exact(oracle, golden, policy):
     state = g['mono_%s_state' % policy]
     assert bank.phase[0] == state[0] and bank.current_pitch[0] == int(state[1])
     assert bank.amplitude[0] == state[2]
+
+
+# ---- output side of an offline bounce (klanggeber.py:81-97, 205-249, wavfile.py:54-63) ----
+@pytest.mark.parametrize('name,ch', [('mono', 1), ('stereo', 2), ('nofade', 2), ('allfade', 1)])
+def test_bounce_pcm_bit_exact(oracle, golden, name, ch):
+    from tests.helpers import bounce_signals
+    g = golden('bounce')
+    duration, fadeout = g[name + '_params']
+    want = g[name + '_pcm']
+    n_blocks = len(want) // B
+    sig = bounce_signals(name, n_blocks, ch)
+    assert sig.sum() == g[name + '_signal_sum'][0] and np.abs(sig).max() == g[name + '_signal_sum'][1]
+    frames, pcm, peak = oracle.bounce(sig.astype(np.float32), duration, fadeout)
+    eq(pcm, want)
+    assert peak == np.abs(frames).max() and np.abs(pcm).max() == 32767
+
+
+def test_bounce_of_silence_has_zero_peak(oracle):
+    frames, pcm, peak = oracle.bounce(np.zeros((3, 1, B), dtype=np.float32), .02, 0.)
+    assert peak == 0. and not pcm.any()

@@ -4,7 +4,7 @@ not bench.py's headline: config 2 (haunting patch, replicated), config 3 in
 materialised mode (per-voice float32 streams written to HBM) and config 4
 (reverb channels, delay lines in HBM).  Usage:
 
-    python tools/bench_configs.py [2] [3m] [3fm] [3fx] [3delay] [4] [4big]
+    python tools/bench_configs.py [2] [3m] [3fm] [3fx] [3delay] [synth] [4] [4big]
 """
 import json
 import os
@@ -121,6 +121,40 @@ def config3_general(ctx, label, **bank_kw):
                 launches=launches)
 
 
+def config_synth(ctx):
+    """2,730 PolyphonicSynthesizers x 24 voices (65,520 voices, saw -> ADSR, gated) under one
+    Mixer; ~6 notes per instrument sounding, note routing on the device (klmi_bank_notes)."""
+    poly, n_inst, n_blocks = 24, 2730, 128
+    n = poly * n_inst
+    bank = native.Bank(ctx, n, has_env=True, poly_voices=poly)
+    bank.set(native.F_WAVE, np.full(n, native.WAVE_SAWTOOTH))
+    bank.set_mix_divisor(poly * n_inst)
+    rng = np.random.default_rng(5)
+    per_inst, runs = 40, 5
+
+    def notes(run):
+        m = n_inst * per_inst
+        nt = np.zeros(2 * m, dtype=native.NOTE_DTYPE)
+        inst = np.repeat(np.arange(n_inst), per_inst)
+        on = rng.integers(0, n_blocks - 8, m)
+        pitch = rng.integers(36, 96, m)
+        nt['instrument'] = np.r_[inst, inst]
+        nt['block'] = np.r_[on, on + rng.integers(1, 24, m).clip(max=n_blocks - 1 - on)] + run * n_blocks
+        nt['pitch'] = np.r_[pitch, pitch]
+        nt['velocity'] = np.r_[.2 + .8 * rng.random(m), np.zeros(m)]
+        nt['frequency'] = np.tile(440. * 2. ** ((pitch - 69) / 12.), 2)
+        return nt
+    bank.notes(np.concatenate([notes(r) for r in range(runs)]))
+    best, med = timed(lambda: bank.render(n_blocks))
+    ms, launches = bank.last_kernel_ms()
+    units = n * n_blocks * B
+    return dict(config='synthesizers: %d PolyphonicSynthesizers x %d voices (saw -> ADSR, gated) -> '
+                       'Mixer, %d notes per synthesizer and render, device-side routing, %d blocks'
+                       % (n_inst, poly, per_inst, n_blocks),
+                value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
+                launches=launches)
+
+
 def config4(ctx, n_channels=4096, n_blocks=512):
     patch = patches.reverb_patch(n_channels=n_channels, n_blocks=n_blocks)
     bank, ev = bank_for(ctx, patch)
@@ -162,6 +196,8 @@ def main():
         elif w == '3delay':
             r = config3_general(ctx, 'Filter -> Delay(6-16 ms) -> Gain',
                                 effects=[native.FX_FILTER, native.FX_DELAY, native.FX_GAIN])
+        elif w == 'synth':
+            r = config_synth(ctx)
         elif w == '4big':
             r = config4(ctx, 16384, 128)
         else:

@@ -36,6 +36,12 @@ def save(name, **arrays):
     print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024.))
 
 
+def bounce_signals(name, n_blocks, channels):
+    """Seeded float64 buffers for the bounce fixtures (the same recipe as tests/helpers.py)."""
+    r = np.random.default_rng(len(name))
+    return (2. * r.random((n_blocks, channels, B)) - 1.) * np.linspace(.2, 1.3, n_blocks)[:, None, None]
+
+
 def main():
     if not ref_loader.reference_available():
         print('reference tree absent: nothing generated')
@@ -556,6 +562,38 @@ def main():
     syn['mono_notes'] = notes_array(script1)
     syn['template'] = np.array([.004, .02, .6, .012])
     save('synthesizer', **syn)
+
+    # ---- output side of an offline bounce -----------------------
+    # klanggeber.py:179-300 run_audio_engine(offline) with the real Dac, fade-out and
+    # write_wave; the "network" just places seeded float64 buffers on the Dac's inputs
+    import tempfile
+    import wave as wavemod
+    from klang.audio.klanggeber import Adc, Dac, run_audio_engine
+    bo = {}
+    for name, ch, duration, fadeout in (('mono', 1, .25, .1), ('stereo', 2, .4, .33),
+                                        ('nofade', 2, .1, 0.), ('allfade', 1, .2, .2)):
+        n_cyc = int(duration * 44100 // B)
+        sig = bounce_signals(name, n_cyc, ch)
+        dac = Dac(nChannels=ch)
+        state = {'k': 0}
+
+        def execute(dac=dac, sig=sig, state=state):
+            for c, inp in enumerate(dac.inputs):
+                inp.set_value(sig[state['k'], c])
+            state['k'] += 1
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, 'b.wav')
+            run_audio_engine(Adc(nChannels=0), dac, execute, duration=duration, fadeout=fadeout,
+                             filepath=path, offline=True)
+            with wavemod.open(path, 'rb') as wf:
+                assert wf.getnchannels() == ch and wf.getsampwidth() == 2
+                pcm = np.frombuffer(wf.readframes(-1), dtype='<i2').reshape(-1, ch)
+        # the inputs are a seeded recipe (tests/helpers.py bounce_signals rebuilds them);
+        # only a checksum is stored
+        bo[name + '_signal_sum'] = np.array([sig.sum(), np.abs(sig).max()])
+        bo[name + '_pcm'] = pcm
+        bo[name + '_params'] = np.array([duration, fadeout])
+    save('bounce', **bo)
 
     # ---- hello_world (config 1): Oscillator(440) | Dac, pre-normalisation ---
     osc = OSC.Oscillator(frequency=440.)
