@@ -306,6 +306,26 @@ int klmi_bank_render_voices_f64(klmi_bank *bank, int first, int count, int n_blo
 int klmi_bank_render_voices_device(klmi_bank *bank, int first, int count, int n_blocks,
                                    float *dev_out);
 
+/* ---- output side of an offline bounce ---------------------------------------- */
+/* run_audio_engine(offline=True) for a patch whose Dac is fed by this bank
+ * (klang/audio/klanggeber.py:179-300): nCycles = int(duration * SAMPLING_RATE //
+ * BUFFER_SIZE) buffers from play time 0 (:258); per buffer Dac.collect_samples /
+ * pack_signals to interleaved float32 (:81-97, 164-176) and, for buffers with
+ * playTime >= duration - fadeout, the np.interp fade-out (:205-209, 243-249); then
+ * write_wave's peak normalisation (klang/audio/wavfile.py:54-63, klang/math.py:14-21):
+ * int16(frames / max|frames| * 32767) in float32.  One device pass instead of one host
+ * round trip per buffer.
+ *   frames [nCycles*256][channels] float32 (optional for _bounce), pcm the same shape
+ *   int16 (optional), peak max|frames|.  A silent piece with pcm requested fails with
+ *   KLMI_E_ARG ("Zero amplitude! Can not normalize!", the reference's ValueError) after
+ *   frames and peak have been delivered.  State, events and notes advance as in
+ *   klmi_bank_render. */
+int klmi_bounce_cycles(double duration);  /* nCycles for a duration (0 if not positive) */
+int klmi_bank_bounce(klmi_bank *bank, double duration, double fadeout, float *host_frames,
+                     int16_t *host_pcm, float *host_peak);
+int klmi_bank_bounce_device(klmi_bank *bank, double duration, double fadeout, float *dev_frames,
+                            int16_t *dev_pcm, float *dev_peak);
+
 /* Reverb delay-line state of one voice: rings concatenated in tap order
  * (sum of tap lengths float64) and the ring positions [n_echos]. */
 int klmi_bank_reverb_state_get(klmi_bank *bank, int voice, double *rings, int32_t *positions);

@@ -16,7 +16,8 @@ from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
 from klang_amd.constants import INF, MONO
 from klang_amd.errors import KlangError
 
-__all__ = ['Adc', 'Dac', 'ChannelMismatch', 'run_audio_engine', 'write_wave', 'pack_signals']
+__all__ = ['Adc', 'Dac', 'ChannelMismatch', 'run_audio_engine', 'write_wave', 'write_pcm',
+           'pack_signals']
 
 D_TYPE = np.float32
 
@@ -87,11 +88,18 @@ def write_wave(audio, filepath, samplingRate=SAMPLING_RATE, dtype=np.int16):
     if peak == 0:
         raise ValueError('Zero amplitude! Can not normalize!')
     samples = (audio / peak * np.iinfo(dtype).max).astype(dtype)
+    write_pcm(samples, filepath, samplingRate)
+
+
+def write_pcm(samples, filepath, samplingRate=SAMPLING_RATE):
+    """(frames, channels) int16 -> PCM WAV file (the container part of wavfile.py:54-63;
+    a device bounce delivers the normalised int16 samples itself)."""
+    samples = np.asarray(samples)
     frames, channels = samples.shape
     assert frames > channels
     with wave.open(filepath, 'wb') as out:
         out.setnchannels(channels)
-        out.setsampwidth(np.dtype(dtype).itemsize)
+        out.setsampwidth(samples.dtype.itemsize)
         out.setframerate(samplingRate)
         out.writeframes(samples.astype('<i2').tobytes())
 

@@ -17,6 +17,7 @@
 
 #include "aux_kernels.h"
 #include "bank_kernels.h"
+#include "bounce_kernels.h"
 #include "mod_kernels.h"
 #include "reverb_kernels.h"
 
@@ -428,6 +429,11 @@ struct klmi_bank {
     DevBuf<double> dev_voices_f64, ext_input, bus_f64;
     int ext_blocks = 0;   // blocks supplied by klmi_bank_set_input
     int ext_cursor = 0;   // blocks of it consumed by renders so far
+
+    // offline bounce (klmi_bank_bounce)
+    DevBuf<float> bounce_frames, bounce_peak;
+    DevBuf<double> bounce_time;
+    DevBuf<int16_t> bounce_pcm;
 
     // reverb (has_reverb)
     ReverbState reverb;
@@ -1542,6 +1548,119 @@ extern "C" int klmi_bank_render_voices_f64(klmi_bank *b, int first, int count, i
     HIP_TRY(hipMemcpyAsync(host_out, b->dev_voices_f64.p, sizeof(double) * len,
                            hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// offline bounce: klanggeber.py:255-263 (nCycles buffers from play time 0), :81-97 pack,
+// :205-209, 243-249 fade-out, wavfile.py:54-63 peak-normalised int16
+// ---------------------------------------------------------------------------------
+extern "C" int klmi_bounce_cycles(double duration)
+{
+    // int(duration * SAMPLING_RATE // BUFFER_SIZE); the division by 256 is exact
+    const double q = std::floor(duration * (double)KLMI_SAMPLING_RATE / (double)KLMI_BUFFER_SIZE);
+    if (!(q >= 0.) || !std::isfinite(q))
+        return 0;   // nothing to render; klmi_bank_bounce rejects such durations
+    return q > 2147483647. ? 2147483647 : (int)q;
+}
+
+// frames / pcm / peak on the device; dev_frames may be the bank's own staging buffer
+static int bounce_device(klmi_bank *b, int n_blocks, double duration, double fadeout,
+                         float *dev_frames, int16_t *dev_pcm, float *dev_peak)
+{
+    hipStream_t st = b->ctx->stream;
+    const int ch = b->desc.stereo ? 2 : 1;
+    const size_t len = (size_t)n_blocks * ch * kBlock;
+    HIP_TRY(b->dev_mix.reserve(len));
+    TRY(render_mix(b, n_blocks, b->dev_mix.p));
+    // playTime += INTERVAL, a running float64 sum (klanggeber.py:199, 248)
+    std::vector<double> play_time(n_blocks);
+    double t = 0.;
+    for (int k = 0; k < n_blocks; ++k) {
+        play_time[k] = t;
+        t += kInterval;
+    }
+    HIP_TRY(b->bounce_time.reserve(n_blocks));
+    HIP_TRY(b->bounce_peak.reserve((size_t)n_blocks));
+    HIP_TRY(hipMemcpyAsync(b->bounce_time.p, play_time.data(), sizeof(double) * n_blocks,
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // play_time dies here
+    const double fade_start = duration - fadeout;
+    if (ch == 2)
+        hipLaunchKernelGGL(bounce_pack_kernel<2>, dim3(n_blocks), dim3(kBlock), 0, st, b->dev_mix.p,
+                           b->bounce_time.p, fade_start, duration, dev_frames, b->bounce_peak.p);
+    else
+        hipLaunchKernelGGL(bounce_pack_kernel<1>, dim3(n_blocks), dim3(kBlock), 0, st, b->dev_mix.p,
+                           b->bounce_time.p, fade_start, duration, dev_frames, b->bounce_peak.p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(bounce_peak_kernel, dim3(1), dim3(256), 0, st, b->bounce_peak.p, n_blocks,
+                       dev_peak);
+    HIP_TRY(hipGetLastError());
+    if (dev_pcm) {
+        const size_t total4 = len / 4;
+        hipLaunchKernelGGL(bounce_pcm_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st,
+                           dev_frames, total4, dev_peak, dev_pcm);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+static int bounce_args(klmi_bank *b, double duration, double fadeout, int *n_blocks)
+{
+    if (!b)
+        return fail(KLMI_E_ARG, "klmi_bank_bounce: null bank");
+    if (!(duration > 0.) || !std::isfinite(duration))
+        return fail(KLMI_E_ARG, "klmi_bank_bounce: Offline mode and duration set to INF (or not "
+                                "positive). You will never get anything.");
+    if (!(fadeout >= 0.))
+        return fail(KLMI_E_ARG, "klmi_bank_bounce: fadeout must be >= 0, got %g", fadeout);
+    *n_blocks = klmi_bounce_cycles(duration);
+    if (*n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_bounce: duration %g s is shorter than one buffer",
+                    duration);
+    if (b->block_clock > 0xFFFFFFFEu - (uint32_t)*n_blocks)
+        return fail(KLMI_E_ARG, "klmi_bank_bounce: block clock would overflow");
+    return 0;
+}
+
+extern "C" int klmi_bank_bounce_device(klmi_bank *b, double duration, double fadeout,
+                                       float *dev_frames, int16_t *dev_pcm, float *dev_peak)
+{
+    int n_blocks = 0;
+    TRY(bounce_args(b, duration, fadeout, &n_blocks));
+    if (!dev_frames || !dev_peak)
+        return fail(KLMI_E_ARG, "klmi_bank_bounce_device: null frames / peak pointer");
+    TRY(use(b->ctx));
+    return bounce_device(b, n_blocks, duration, fadeout, dev_frames, dev_pcm, dev_peak);
+}
+
+extern "C" int klmi_bank_bounce(klmi_bank *b, double duration, double fadeout, float *host_frames,
+                                int16_t *host_pcm, float *host_peak)
+{
+    int n_blocks = 0;
+    TRY(bounce_args(b, duration, fadeout, &n_blocks));
+    TRY(use(b->ctx));
+    hipStream_t st = b->ctx->stream;
+    const size_t len = (size_t)n_blocks * (b->desc.stereo ? 2 : 1) * kBlock;
+    HIP_TRY(b->bounce_frames.reserve(len + 4));  // + the peak, behind the frames
+    float *dev_peak = b->bounce_frames.p + len;
+    if (host_pcm)
+        HIP_TRY(b->bounce_pcm.reserve(len));
+    TRY(bounce_device(b, n_blocks, duration, fadeout, b->bounce_frames.p,
+                      host_pcm ? b->bounce_pcm.p : nullptr, dev_peak));
+    float peak = 0.f;
+    HIP_TRY(hipMemcpyAsync(&peak, dev_peak, sizeof(float), hipMemcpyDeviceToHost, st));
+    if (host_frames)
+        HIP_TRY(hipMemcpyAsync(host_frames, b->bounce_frames.p, sizeof(float) * len,
+                               hipMemcpyDeviceToHost, st));
+    if (host_pcm)
+        HIP_TRY(hipMemcpyAsync(host_pcm, b->bounce_pcm.p, sizeof(int16_t) * len,
+                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (host_peak)
+        *host_peak = peak;
+    if (host_pcm && peak == 0.f)
+        return fail(KLMI_E_ARG, "Zero amplitude! Can not normalize!");  // math.py:17-19
     return 0;
 }
 

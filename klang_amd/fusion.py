@@ -380,6 +380,19 @@ class GpuVoiceBank(Block):
             self.remaining -= 1
         self.sink.output.set_value(self._ready.pop().astype(np.float64))
 
+    def bounce(self, duration, fadeout=0., want_pcm=True):
+        """The whole piece in one device pass (klmi_bank_bounce): notes queued so far are
+        applied at buffer 0 as usual; -> (frames float32 [cycles*256][channels], int16 pcm)."""
+        if self._ready:
+            raise KlangError('GpuVoiceBank.bounce: buffers were already rendered ahead')
+        self._collect_events()
+        frames, pcm, _ = self.bank.bounce(duration, fadeout, want_pcm)
+        if self.remaining is not None:
+            self.remaining = 0
+        last = frames[-BUFFER_SIZE:].T.astype(np.float64)
+        self.sink.output.set_value(last if self.stereo else last[0])
+        return frames, pcm
+
     def sync_host_blocks(self):
         """Copy device state back into the host blocks (currentPhase, envelope
         stage/value) so that the patch can be inspected or re-run on the host."""

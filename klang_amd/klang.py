@@ -10,7 +10,8 @@ evaluation of the same blocks (plumbing / reference behaviour, no GPU).
 import collections
 import logging
 
-from klang_amd.audio.engine import Adc, Dac, look_for_audio_blocks, run_audio_engine  # noqa: F401
+from klang_amd.audio.engine import (Adc, Dac, look_for_audio_blocks, run_audio_engine,  # noqa: F401
+                                    write_pcm)
 from klang_amd.composite import Composite
 from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
 from klang_amd.constants import INF
@@ -36,6 +37,36 @@ def validate_global_execution_order(execOrder, logger):
     if dup:
         logger.warning('Found duplicates in flattened execOrder! Following blocks will get '
                        'executed multiple times per buffer cycle!\n%s', '\n'.join(dup))
+
+
+def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', offline=False):
+    """The whole offline bounce in one device pass (klmi_bank_bounce), or None when the patch
+    is not of that kind: exactly one device bank feeding the Dac directly, nothing else in the
+    order.  Packing, fade-out and the peak-normalised int16 samples (klanggeber.py:81-97,
+    205-249, wavfile.py:54-63) then happen on the device; the host only writes the container."""
+    from klang_amd import fusion, native
+    if not offline or duration == INF or adc.nChannels:
+        return None
+    banks = [b for b in execOrder if isinstance(b, fusion.GpuVoiceBank)]
+    if len(banks) != 1 or any(b is not banks[0] and b is not dac for b in execOrder):
+        return None
+    bank = banks[0]
+    feeds = [i.incomingConnection for i in dac.inputs if i.incomingConnection is not None]
+    if (feeds != [bank.sink.output] or dac.inputs[0].incomingConnection is None
+            or bank.bank.channels != dac.nChannels):
+        return None
+    if int(duration * SAMPLING_RATE // BUFFER_SIZE) < 1:
+        return None
+    try:
+        frames, pcm = bank.bounce(duration, fadeout, want_pcm=bool(filepath))
+    except native.NativeError as err:
+        if err.code == native.E_ARG and 'Zero amplitude' in str(err):
+            raise ValueError(str(err)) from None     # math.py:17-19
+        raise
+    if filepath:
+        logging.getLogger('KlangGeber').info('Writing audio dump to WAV file %r', filepath)
+        write_pcm(pcm, filepath)
+    return list(frames.reshape(-1, BUFFER_SIZE, dac.nChannels))
 
 
 def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
@@ -71,6 +102,10 @@ def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
             block.update()
 
     try:
+        if backend == 'hip':
+            frames = device_bounce(execOrder, adc, dac, **kwargs)
+            if frames is not None:
+                return frames
         return run_audio_engine(adc, dac, execute_all_blocks, **kwargs)
     finally:
         for bank in banks:

@@ -61,7 +61,8 @@ EXPORTS = [
     'klmi_bank_set_mix_divisor', 'klmi_bank_set_input',
     'klmi_bank_render', 'klmi_bank_render_device', 'klmi_bank_render_voices',
     'klmi_bank_render_voices_f64', 'klmi_bank_render_voices_device', 'klmi_bank_reverb_state_get',
-    'klmi_bank_last_kernel_ms', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
+    'klmi_bank_last_kernel_ms', 'klmi_bounce_cycles', 'klmi_bank_bounce',
+    'klmi_bank_bounce_device', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
     'klmi_env_get', 'klmi_env_gate', 'klmi_env_sample', 'klmi_env_active', 'klmi_comb_create',
     'klmi_comb_destroy', 'klmi_comb_set_alpha', 'klmi_comb_filter',
 ]
@@ -128,6 +129,9 @@ def load():
     L.klmi_bank_render_voices_f64.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     L.klmi_bank_render_voices_device.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp]
     L.klmi_bank_reverb_state_get.argtypes = [_vp, C.c_int, _dp, _ip]
+    L.klmi_bounce_cycles.argtypes = [C.c_double]
+    L.klmi_bank_bounce.argtypes = [_vp, C.c_double, C.c_double, _vp, _vp, _fp]
+    L.klmi_bank_bounce_device.argtypes = [_vp, C.c_double, C.c_double, _vp, _vp, _vp]
     L.klmi_bank_last_kernel_ms.argtypes = [_vp, _fp, C.POINTER(C.c_int)]
     L.klmi_env_create.argtypes = [_vp, C.c_int] + [C.c_double] * 6 + [C.c_int, C.c_int,
                                                                        C.POINTER(_vp)]
@@ -407,6 +411,25 @@ class Bank:
         count = self.n - first if count is None else count
         _check(load().klmi_bank_render_voices_device(self._h, first, count, int(n_blocks),
                                                      _vp(dev_ptr)))
+
+    def bounce(self, duration, fadeout=0., want_pcm=True):
+        """Offline bounce of the whole piece on the device (klmi_bank_bounce):
+        -> (frames float32 [cycles*256][channels], int16 pcm or None, peak).  Raises
+        NativeError (E_ARG) for a silent piece when pcm is wanted, like write_wave."""
+        cycles = load().klmi_bounce_cycles(float(duration)) if np.isfinite(duration) else 0
+        shape = (max(cycles, 0) * BUFFER_SIZE, self.channels)
+        frames = np.empty(shape, dtype=np.float32)
+        pcm = np.empty(shape, dtype=np.int16) if want_pcm else None
+        peak = C.c_float(0.)
+        _check(load().klmi_bank_bounce(self._h, float(duration), float(fadeout),
+                                       frames.ctypes.data_as(_vp),
+                                       pcm.ctypes.data_as(_vp) if want_pcm else None,
+                                       C.byref(peak)))
+        return frames, pcm, peak.value
+
+    def bounce_device(self, duration, fadeout, frames_ptr, pcm_ptr, peak_ptr):
+        _check(load().klmi_bank_bounce_device(self._h, float(duration), float(fadeout),
+                                              frames_ptr, pcm_ptr, peak_ptr))
 
     def reverb_state(self, voice):
         taps, _ = reverb_design(self.desc.reverb_decay, self.desc.reverb_pre_delay,
