@@ -142,7 +142,8 @@ typedef enum {
                                k2 smoothness, k3 dutyCycle; state k0 lfo phase, k1 zi */
     KLMI_FX_DELAY = 7       /* Delay (effects.py:136-174): k0 time (s, <= 2; at least one
                                buffer: 256 samples), k1 feedback, k2 drywet; state k0 ring
-                               position.  Setting k0 clears the delay line. */
+                               position.  Setting k0 (of any voice) empties every delay line
+                               of the bank at the next render. */
 } klmi_fx_kind;
 #define KLMI_MAX_FX 8
 #define KLMI_F_FX(stage, k) (64 + 4 * (stage) + (k))        /* parameter k = 0..3 of a stage */

@@ -58,8 +58,9 @@ struct BankView {
     unsigned char fx_kind[8];  // FxKind
     const double *fx_par;      // [8][kFxSlots][n] per-stage device parameters
     double *fx_state;          // [8][2][n]: tremolo lfo phase, zi; delay position
-    double *fx_ring;           // the delay stage's rings, [fx_ring_cap][n] (slot-major)
-    int fx_ring_cap;
+    double *fx_ring;           // the delay stage's lines, [n][fx_ring_stride] (voice-major: ring
+                               // positions differ per voice); slots [len, len+8) mirror [0, 8)
+    int fx_ring_stride;
     // synthesizers: activity gating and device-side note routing
     int gated;                  // voices are only updated while Voice.active
     int poly;                   // voices per PolyphonicSynthesizer, 0: none

@@ -395,7 +395,9 @@ struct klmi_bank {
     // host, what the kernel needs [8][kFxSlots][n] on the device, the delay stage's rings
     std::vector<double> fx_raw;
     DevBuf<double> fx_par, fx_ring, fx_ring_backup;
-    int fx_ring_cap = 0;                 // slots per voice; 0 = not allocated yet
+    int fx_ring_cap = 0;                 // longest line of the bank; 0 = not allocated yet
+    int fx_ring_stride = 0;              // doubles per voice row: capacity + 8 mirror slots,
+                                         // rounded up to whole 128-byte lines
     int fx_delay_stage = -1;
     DevBuf<double> lfo_par, mod_par;    // [3][n] frequency, scale, offset (allocated when used)
     DevBuf<int32_t> lfo_wave, mod_wave;
@@ -500,7 +502,7 @@ static BankView make_view(klmi_bank *b)
     v.fx_par = b->fx_par.p;
     v.fx_state = b->desc.n_fx ? b->f64(SL_FX_STATE) : nullptr;
     v.fx_ring = b->fx_ring.p;
-    v.fx_ring_cap = b->fx_ring_cap;
+    v.fx_ring_stride = b->fx_ring_stride;
     v.gated = b->desc.gated || b->desc.poly_voices > 0;
     v.poly = b->desc.poly_voices;
     v.nt_offset = b->nt_offset.p;
@@ -602,8 +604,8 @@ static int upload_fx(klmi_bank *b, int stage, int first, int count)
     return 0;
 }
 
-// The delay stage's rings [capacity][n], capacity = the longest line of the bank;
-// (re)allocated zeroed when the capacity changed (ring_buffer.py:42 zero-initialised).
+// The delay stage's lines [n][stride], stride >= the longest line of the bank + 8 mirror
+// slots; (re)allocated zeroed when the capacity changed (ring_buffer.py:42 zero-initialised).
 static int ensure_fx_ring(klmi_bank *b)
 {
     if (b->fx_delay_stage < 0)
@@ -618,11 +620,13 @@ static int ensure_fx_ring(klmi_bank *b)
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     b->fx_ring.release();
     b->fx_ring_backup.release();
-    hipError_t e = b->fx_ring.alloc((size_t)cap * n);
+    const int stride = (cap + 8 + 15) & ~15;
+    hipError_t e = b->fx_ring.alloc((size_t)stride * n);
     if (e != hipSuccess)
         return fail(KLMI_E_MEMORY, "delay lines (%d samples x %d voices) do not fit: %s", cap, b->n,
                     hipGetErrorString(e));
-    HIP_TRY(hipMemset(b->fx_ring.p, 0, sizeof(double) * (size_t)cap * n));
+    HIP_TRY(hipMemset(b->fx_ring.p, 0, sizeof(double) * (size_t)stride * n));
+    b->fx_ring_stride = stride;
     HIP_TRY(hipMemset(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage), 0, sizeof(double) * n));
     b->fx_ring_cap = cap;
     return 0;
@@ -885,6 +889,8 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
             }
         }
         std::copy(host, host + count, b->fx_raw.begin() + ((size_t)stage * 4 + k) * b->n + first);
+        if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0)
+            b->fx_ring_cap = 0;  // new lengths: the lines (and their mirror slots) start empty
         return upload_fx(b, stage, first, count);
     }
     switch (field) {
@@ -1475,7 +1481,7 @@ static int render_preview(klmi_bank *b, int first, int count, int n_blocks, void
     TRY(ensure_fx_ring(b));
     hipStream_t st = b->ctx->stream;
     const size_t n = (size_t)b->n;
-    const size_t ring_len = (size_t)b->fx_ring_cap * n;
+    const size_t ring_len = (size_t)b->fx_ring_stride * n;
     if (ring_len) {  // the delay lines are state too
         if (ring_len * sizeof(double) > ((size_t)1 << 30))
             return fail(KLMI_E_STATE, "klmi_bank_render_voices: previews of banks with more than "

@@ -69,6 +69,11 @@ __device__ __forceinline__ void wave_block(int sel, int lane_wave, const double 
     }
 }
 
+// two float64 at 8-byte alignment (one 16-byte access)
+struct __attribute__((packed, aligned(8))) Double2U {
+    double a, b;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_env, int has_filter,
                                                            int first, int count, int block_base,
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     }
     int delay_pos = 0, delay_len = 1;
     double delay_fb = 0., delay_dw = 0.;
+    double *delay_line = bk.fx_ring + (size_t)v * bk.fx_ring_stride;
     if (delay_stage >= 0) {
         const double *par = bk.fx_par + (size_t)(delay_stage * kFxSlots) * n + v;
         delay_pos = (int)bk.fx_state[(size_t)(2 * delay_stage) * n + v];
@@ -441,22 +447,40 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             break;
                         case FX_DELAY: {    // effects.py:166-174 (the blend reads the window after
                                             // the write: wet = new + feedback * delayed)
-                            double *slot[8];
-                            double old[8];
+                            // The voice's own line is contiguous (positions differ from voice to
+                            // voice, so nothing coalesces ACROSS lanes: a lane's 8 slots = 64 B of
+                            // one cache line).  Slots [len, len+8) mirror slots [0, 8), so the 8
+                            // reads never wrap; length >= a buffer, so they never see this
+                            // block's writes.
+                            int idx0 = delay_pos + c * CH + i8;
+                            idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
+                            double *line = delay_line + idx0;
+                            double w[8];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                int idx = delay_pos + c * CH + i8 + j;
-                                idx = idx >= delay_len ? idx - delay_len : idx;  // length >= a buffer
-                                slot[j] = bk.fx_ring + (size_t)idx * n + v;
-                                old[j] = *slot[j];
+                            for (int j = 0; j < 8; j += 2) {
+                                const Double2U old = reinterpret_cast<const Double2U *>(line)[j >> 1];
+                                w[j] = x[j] + delay_fb * old.a;
+                                w[j + 1] = x[j + 1] + delay_fb * old.b;
+                            }
+                            if (live) {
+#pragma unroll
+                                for (int j = 0; j < 8; j += 2)
+                                    reinterpret_cast<Double2U *>(line)[j >> 1] = Double2U{w[j], w[j + 1]};
+                                // keep slots and mirror in step where the 8 touch either end
+                                if (idx0 < 8 || idx0 + 8 > delay_len) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) {
+                                        const int idx = idx0 + j;
+                                        if (idx >= delay_len)
+                                            delay_line[idx - delay_len] = w[j];
+                                        else if (idx < 8)
+                                            delay_line[idx + delay_len] = w[j];
+                                    }
+                                }
                             }
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const double w = x[j] + delay_fb * old[j];
-                                if (live)
-                                    *slot[j] = w;
-                                x[j] = (1. - delay_dw) * x[j] + delay_dw * w;
-                            }
+                            for (int j = 0; j < 8; ++j)
+                                x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
                             break;
                         }
                         default:
