@@ -16,7 +16,8 @@ namespace klmi {
 
 // t[n] = DT * n, n = 0..256 (helpers.py:27-32), padded to whole groups of 8
 constexpr int kTimeSlots = kBlock + 8;
-__constant__ __attribute__((aligned(64))) double c_time[kTimeSlots];
+// one copy per translation unit (each uploads its own: launch.h upload_time_table_*)
+static __constant__ __attribute__((aligned(64))) double c_time[kTimeSlots];
 struct __attribute__((aligned(64))) Time8 {
     double t[8];
 };
@@ -496,51 +497,6 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
         }
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
     }
-}
-
-// Deterministic bus reduction in two steps (no float atomics anywhere):
-//   stage[slice][s] = sum of the partial rows of `slice` (ascending, float64)
-//   bus[s]          = (sum of the slices, ascending, float64) / divisor -> float32
-// The slice count depends on the row count only, so the association is fixed for
-// a given bank size.  One thread owns 4 consecutive samples (16-byte loads).
-constexpr int kBusSlices = 32;
-
-__host__ __device__ inline int bus_slices(int n_rows)
-{
-    return n_rows < kBusSlices ? n_rows : kBusSlices;
-}
-
-// grid = (ceil(bus_len / 1024), slices), block = 256; bus_len is a multiple of 256
-__global__ __launch_bounds__(256) void bus_slice_kernel(const float *__restrict__ partial,
-                                                        int n_rows, size_t bus_len,
-                                                        double *__restrict__ stage)
-{
-    const size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (s >= bus_len)
-        return;
-    const int slices = gridDim.y;
-    const int r0 = (int)((long long)n_rows * blockIdx.y / slices);
-    const int r1 = (int)((long long)n_rows * (blockIdx.y + 1) / slices);
-    double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
-#pragma unroll 4
-    for (int r = r0; r < r1; ++r) {
-        const float4 p = *reinterpret_cast<const float4 *>(partial + (size_t)r * bus_len + s);
-        a0 += (double)p.x, a1 += (double)p.y, a2 += (double)p.z, a3 += (double)p.w;
-    }
-    double *o = stage + (size_t)blockIdx.y * bus_len + s;
-    o[0] = a0, o[1] = a1, o[2] = a2, o[3] = a3;
-}
-
-__global__ void bus_finish_kernel(const double *__restrict__ stage, int slices, size_t bus_len,
-                                  double divisor, float *__restrict__ bus)
-{
-    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= bus_len)
-        return;
-    double acc = 0.;
-    for (int k = 0; k < slices; ++k)
-        acc += stage[(size_t)k * bus_len + s];
-    bus[s] = (float)(acc / divisor);
 }
 
 }  // namespace klmi

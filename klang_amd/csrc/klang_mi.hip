@@ -18,7 +18,8 @@
 #include "aux_kernels.h"
 #include "bank_kernels.h"
 #include "bounce_kernels.h"
-#include "mod_kernels.h"
+#include "bus_kernels.h"
+#include "launch.h"
 #include "reverb_kernels.h"
 
 using namespace klmi;
@@ -259,7 +260,11 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         e = hipMemcpy(ctx->d_table.p, ctx->table.data(), ctx->table.size() * sizeof(double),
                       hipMemcpyHostToDevice);
     if (e == hipSuccess)
-        e = hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof t);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof t);   // this unit's (bounce kernels)
+    if (e == hipSuccess)
+        e = upload_time_table_voice(t);
+    if (e == hipSuccess)
+        e = upload_time_table_mod(t);
     if (e != hipSuccess) {
         delete ctx;
         return fail(KLMI_E_DEVICE, "context setup failed: %s", hipGetErrorString(e));
@@ -1277,61 +1282,8 @@ static int sync_notes(klmi_bank *b)
     return 0;
 }
 
-template <int MODE> static size_t smem_bytes()
-{
-    using TT = TileTraits<MODE>;
-    const int planes = TT::planes ? TT::planes : 1;
-    size_t bytes = sizeof(typename TT::T) * (size_t)kWavesPerGroup * planes * TT::chunk * TT::stride;
-    return bytes;
-}
-
-template <bool ENV, bool FILT, int MODE>
-static hipError_t launch_voice(hipStream_t st, const BankView &view, int first, int count,
-                               int block_base, uint32_t clock_base, int n_blocks, int span_total,
-                               float *partial, void *out)
-{
-    static bool configured[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t smem = smem_bytes<MODE>();
-    auto kernel = voice_kernel<ENV, FILT, MODE>;
-    if (dev < 16 && !configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess)
-            return e;
-        configured[dev] = true;
-    }
-    const int groups = (count + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(kernel, dim3(groups), dim3(kGroup), smem, st, view, first, count,
-                       block_base, clock_base, n_blocks, span_total, partial, out);
-    return hipGetLastError();
-}
-
-// chains with an audio-rate modulation input: exact per-sample kernel (mod_kernels.h)
-template <int MODE>
-static hipError_t launch_mod(bool env, bool filt, hipStream_t st, const BankView &view, int first,
-                             int count, int block_base, uint32_t clock_base, int n_blocks,
-                             int span_total, float *partial, void *out)
-{
-    static bool configured[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t smem = smem_bytes<MODE>();
-    auto kernel = voice_mod_kernel<MODE>;
-    if (dev < 16 && !configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess)
-            return e;
-        configured[dev] = true;
-    }
-    const int groups = (count + kGroup - 1) / kGroup;
-    hipLaunchKernelGGL(kernel, dim3(groups), dim3(kGroup), smem, st, view, (int)env, (int)filt, first,
-                       count, block_base, clock_base, n_blocks, span_total, partial, out);
-    return hipGetLastError();
-}
-
+// The fast kernel for plain [Filter] chains, the general one for everything else
+// (voice_tu.hip / mod_tu.hip).
 template <int MODE>
 static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const BankView &view,
                                  int first, int count, int block_base, uint32_t clock_base,
@@ -1339,19 +1291,10 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
 {
     const bool plain_chain = view.n_fx == 0 || (view.n_fx == 1 && view.fx_kind[0] == FX_FILTER);
     if (view.mod_target != MT_NONE || !plain_chain || view.gated)
-        return launch_mod<MODE>(env, filt, st, view, first, count, block_base, clock_base, n_blocks,
-                                span_total, partial, out);
-    if (env && filt)
-        return launch_voice<true, true, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
-                                              span_total, partial, out);
-    if (env)
-        return launch_voice<true, false, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
-                                               span_total, partial, out);
-    if (filt)
-        return launch_voice<false, true, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
-                                               span_total, partial, out);
-    return launch_voice<false, false, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
-                                            span_total, partial, out);
+        return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
+                                 n_blocks, span_total, partial, out);
+    return launch_voice_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
+                               n_blocks, span_total, partial, out);
 }
 
 static int check_external(klmi_bank *b, int n_blocks)

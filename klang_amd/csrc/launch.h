@@ -1,0 +1,29 @@
+// launch.h -- host-side entry points of the two big kernel families.  Each family is a
+// translation unit of its own (voice_tu.hip: voice_kernel<ENV,FILT,MODE>, mod_tu.hip:
+// voice_mod_kernel<MODE>) so that the library builds in parallel and an edit to the host
+// code does not recompile them.
+#pragma once
+#include "bank_kernels.h"
+
+namespace klmi {
+
+// t[n] = DT * n into the unit's own constant table (kTimeSlots doubles)
+hipError_t upload_time_table_voice(const double *t);
+hipError_t upload_time_table_mod(const double *t);
+
+// grid = ceil(count / 256) workgroups; `mode` is an OutMode
+hipError_t launch_voice_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
+                               int first, int count, int block_base, uint32_t clock_base,
+                               int n_blocks, int span_total, float *partial, void *out);
+hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
+                             int first, int count, int block_base, uint32_t clock_base,
+                             int n_blocks, int span_total, float *partial, void *out);
+
+template <int MODE> inline size_t tile_bytes()
+{
+    using TT = TileTraits<MODE>;
+    const int planes = TT::planes ? TT::planes : 1;
+    return sizeof(typename TT::T) * (size_t)kWavesPerGroup * planes * TT::chunk * TT::stride;
+}
+
+}  // namespace klmi
