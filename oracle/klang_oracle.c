@@ -575,7 +575,7 @@ static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
     }
     const size_t n = (size_t)bk->n_voices;
     for (int s = 0; s < bk->n_fx; ++s) {
-        const double *par = bk->fx_par + (size_t)s * 4 * n + v;     /* par[k * n] */
+        const double *par = bk->fx_par + (size_t)s * KO_FX_PARAMS * n + v; /* par[k * n] */
         double *state = bk->fx_state + (size_t)s * 2 * n + v;
         switch (bk->fx_kind[s]) {
         case KO_FX_FILTER:
@@ -628,6 +628,36 @@ static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
                 buf[i] = (1. - drywet) * buf[i] + drywet * w; /* math.py:68-75 blend */
             }
             state[0] = (double)((pos + KO_BUFFER_SIZE) % length);
+            break;
+        }
+        case KO_FX_SUBSAMPLE: { /* effects.py:400-415: np.repeat(x[::skip], skip) */
+            const int skip = (int)par[0];
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                buf[i] = buf[i - i % skip];
+            break;
+        }
+        case KO_FX_BITCRUSH: { /* effects.py:434-447 with wavfile.py:14-30: float64 ->
+            int16 (C cast: truncation, low 16 bits), arithmetic shifts, / 32768 */
+            const int bits = (int)par[0];
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+                const int16_t q = (int16_t)(int32_t)(32767. * buf[i]);
+                const int16_t c = (int16_t)((int16_t)(q >> bits) << bits);
+                buf[i] = (double)c / 32768.;
+            }
+            break;
+        }
+        case KO_FX_RINGMOD: { /* effects.py:618-662: lfo -> modulator frequency array ->
+            sine AM signal -> blend(x, am * x, dryWet) */
+            const double frequency = par[0], rate = par[n], amount = par[2 * n], drywet = par[3 * n];
+            double lfo[KO_BUFFER_SIZE], am[KO_BUFFER_SIZE];
+            ko_sample_phase_const(rate, state[0], phase, &state[0]);
+            ko_wave((int)par[4 * n], phase, KO_BUFFER_SIZE, .5, lfo);
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                lfo[i] = frequency + amount * lfo[i];
+            ko_sample_phase_array(lfo, state[n], phase, &state[n]);
+            ko_wave(KO_WAVE_SINE, phase, KO_BUFFER_SIZE, .5, am);
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                buf[i] = (1. - drywet) * buf[i] + drywet * (am[i] * buf[i]);
             break;
         }
         default:

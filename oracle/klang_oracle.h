@@ -146,8 +146,9 @@ typedef struct {
      * 452-561).  n_fx == 0: the chain is just [Filter] when has_filter. */
     int n_fx;
     int fx_kind[8];            /* KO_FX_* */
-    double *fx_par;            /* [8][4][n_voices] parameters as the blocks take them */
-    double *fx_state;          /* [8][2][n_voices]: tremolo lfo phase, zi; delay position */
+    double *fx_par;            /* [8][KO_FX_PARAMS][n_voices] parameters as the blocks take them */
+    double *fx_state;          /* [8][2][n_voices]: tremolo lfo phase, zi; delay position;
+                                  ring modulator lfo phase, modulator phase */
     double *fx_ring;           /* the delay stage's rings, [n_voices][fx_ring_capacity] */
     int fx_ring_capacity;
 } ko_bank;
@@ -160,8 +161,12 @@ enum {
     KO_FX_TANH = 4,       /* p0 drive */
     KO_FX_OCTAVE = 5,
     KO_FX_TREMOLO = 6,    /* p0 rate, p1 depth, p2 smoothness, p3 dutyCycle */
-    KO_FX_DELAY = 7       /* p0 time (s), p1 feedback, p2 drywet; length >= one buffer */
+    KO_FX_DELAY = 7,      /* p0 time (s), p1 feedback, p2 drywet; length >= one buffer */
+    KO_FX_SUBSAMPLE = 8,  /* p0 factor (2..128, power of 2) */
+    KO_FX_BITCRUSH = 9,   /* p0 nBits (0..15) */
+    KO_FX_RINGMOD = 10    /* p0 frequency, p1 rate, p2 amount, p3 dryWet, p4 lfo wave */
 };
+#define KO_FX_PARAMS 8
 
 enum {
     KO_MOD_NONE = 0,

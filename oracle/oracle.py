@@ -80,7 +80,9 @@ class Bank(C.Structure):
     ]
 
 
-FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY = range(8)
+FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY, \
+    FX_SUBSAMPLE, FX_BITCRUSH, FX_RINGMOD = range(11)
+FX_PARAMS = 8
 
 
 MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)
@@ -384,12 +386,12 @@ class OracleBank:
         self.mod_wave = np.zeros(n, dtype=np.int32)
         # effect stages (none by default)
         self.fx_kind = []
-        self.fx_par = np.zeros((8, 4, n))
+        self.fx_par = np.zeros((8, FX_PARAMS, n))
         self.fx_state = np.zeros((8, 2, n))
         self.fx_ring = np.zeros((n, 1))
 
     def set_effects(self, stages):
-        """stages: [(FX_* kind, p0, p1, p2, p3)], each p a scalar or [n] array."""
+        """stages: [(FX_* kind, p0, p1, ...)], each p a scalar or [n] array."""
         self.fx_kind = [int(st[0]) for st in stages]
         self.fx_par[:] = 0.
         self.fx_state[:] = 0.

@@ -496,6 +496,14 @@ def _fx_bank(oracle, golden, stages, has_env=False, has_filter=False):
     ('tremolo_square', ('FX_TREMOLO', 7., .5, 0., .5), 30, 0.),
     ('delay', ('FX_DELAY', .01, .6, .4), 40, 0.),
     ('delay_long', ('FX_DELAY', .0437, .9, .5), 40, 0.),
+    ('subsample_4', ('FX_SUBSAMPLE', 4), 6, 0.),
+    ('subsample_64', ('FX_SUBSAMPLE', 64), 6, 0.),
+    ('bitcrush_5', ('FX_BITCRUSH', 5), 12, 0.),
+    ('bitcrush_0', ('FX_BITCRUSH', 0), 6, 0.),
+    ('bitcrush_13', ('FX_BITCRUSH', 13), 6, 0.),
+    ('ringmod_square', ('FX_RINGMOD', 500., 2., 20., .8, 1), 40, 1e-13),   # sine AM: libm ulps
+    ('ringmod_sine', ('FX_RINGMOD', 500., 2., 20., .8, 0), 40, 1e-10),     # ... inside the cumsum
+    ('ringmod_triangle', ('FX_RINGMOD', 500., 2., 20., .8, 3), 40, 1e-13),
 ])
 def test_effect_stage(oracle, golden, key, stage, n_blocks, tol):
     g = golden('effects')
@@ -509,6 +517,25 @@ def test_effect_stage(oracle, golden, key, stage, n_blocks, tol):
         eq(bank.fx_state[0, :, 0], g['tremolo_final'])
     if key == 'delay':
         assert bank.fx_state[0, 0, 0] == g['delay_final_pos_length'][0]
+    if key.startswith('ringmod'):
+        np.testing.assert_allclose(bank.fx_state[0, :, 0], g[key + '_final'], rtol=0, atol=1e-9)
+        if key != 'ringmod_sine':
+            assert bank.fx_state[0, 0, 0] == g[key + '_final'][0]
+
+
+def test_bitcrusher_wraps_like_the_reference(oracle):
+    """|x| > 1 overflows int16 in convert_samples_to_int (wavfile.py:23-30): the C cast keeps
+    the low 16 bits; checked against the value the real reference returned for x = -1.2 .. 1.2
+    (0.79980469 at x = -1.2, -0.80029297 at x = +1.2, nBits = 4)."""
+    bank = oracle.OracleBank(1, False, False, False)
+    bank.wave[:] = oracle.WAVE_IDS['sawtooth']
+    bank.frequency[:] = 0.
+    bank.set_effects([(oracle.FX_TRANSFORM, 0., -1.2), (oracle.FX_BITCRUSH, 4)])
+    mix, _ = bank.render(1)
+    assert abs(mix[0, 0, 0] - 0.79980469) < 1e-8
+    bank.set_effects([(oracle.FX_TRANSFORM, 0., 1.2), (oracle.FX_BITCRUSH, 4)])
+    mix, _ = bank.render(1)
+    assert abs(mix[0, 0, 0] + 0.80029297) < 1e-8
 
 
 def test_effect_chain_after_a_voice(oracle, golden):

@@ -484,6 +484,18 @@ def main():
     fx['delay_final_pos_length'] = np.array([dl.ring.pos, dl.ring.length])
     fx['delay_long'], _ = fx_run(lambda: FX.Delay(time=.0437, feedback=.9, drywet=.5), n_blocks=40)
 
+    fx['subsample_4'], _ = fx_run(lambda: FX.Subsampler(4), n_blocks=6)
+    fx['subsample_64'], _ = fx_run(lambda: FX.Subsampler(64), n_blocks=6)
+    fx['bitcrush_5'], _ = fx_run(lambda: FX.Bitcrusher(5), n_blocks=12)
+    fx['bitcrush_0'], _ = fx_run(lambda: FX.Bitcrusher(0), n_blocks=6)
+    fx['bitcrush_13'], _ = fx_run(lambda: FX.Bitcrusher(13), n_blocks=6)
+    for wname in ('square', 'sine', 'triangle'):
+        out, rm = fx_run(lambda: FX.RingModulator(frequency=500., rate=2., amount=20.,
+                                                  wave_func=W.WAVE_FUNCTIONS[wname], dryWet=.8),
+                         n_blocks=40)
+        fx['ringmod_' + wname] = out
+        fx['ringmod_%s_final' % wname] = np.array([rm.lfo.currentPhase, rm.modulator.currentPhase])
+
     # voice -> Filter -> TanhDistortion -> Tremolo -> Delay -> Gain
     voice = A.Voice(OSC.Oscillator(wave_func=W.sawtooth), A.ADSR(.01, .05, .6, .04))
     stages = [FX.Filter(frequency=1500.), FX.TanhDistortion(1.5),
