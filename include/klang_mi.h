@@ -140,13 +140,20 @@ typedef enum {
     KLMI_FX_OCTAVE = 5,     /* OctaveDistortion (effects.py:452-466) */
     KLMI_FX_TREMOLO = 6,    /* Tremolo (effects.py:73-133): k0 rate (Hz), k1 depth,
                                k2 smoothness, k3 dutyCycle; state k0 lfo phase, k1 zi */
-    KLMI_FX_DELAY = 7       /* Delay (effects.py:136-174): k0 time (s, <= 2; at least one
+    KLMI_FX_DELAY = 7,      /* Delay (effects.py:136-174): k0 time (s, <= 2; at least one
                                buffer: 256 samples), k1 feedback, k2 drywet; state k0 ring
                                position.  Setting k0 (of any voice) empties every delay line
                                of the bank at the next render. */
+    KLMI_FX_SUBSAMPLE = 8,  /* Subsampler (effects.py:388-417): k0 factor, a power of 2 in 2..128 */
+    KLMI_FX_BITCRUSH = 9,   /* Bitcrusher (effects.py:420-449): k0 nBits in 0..15; samples go
+                               through int16 like convert_samples_to_int (wavfile.py:23-30) */
+    KLMI_FX_RINGMOD = 10    /* RingModulator (effects.py:618-662): k0 frequency, k1 rate,
+                               k2 amount, k3 dryWet, k4 the Lfo's klmi_wave (sine..triangle);
+                               state k0 lfo phase, k1 modulator phase */
 } klmi_fx_kind;
 #define KLMI_MAX_FX 8
-#define KLMI_F_FX(stage, k) (64 + 4 * (stage) + (k))        /* parameter k = 0..3 of a stage */
+#define KLMI_FX_PARAMS 8
+#define KLMI_F_FX(stage, k) (64 + KLMI_FX_PARAMS * (stage) + (k)) /* parameter k = 0..7 of a stage */
 #define KLMI_F_FX_STATE(stage, k) (128 + 2 * (stage) + (k)) /* state k = 0..1 of a stage */
 
 /* What one bank evaluates per voice, in the reference's terms:
@@ -156,8 +163,8 @@ typedef enum {
  *   x   = has_filter ? Filter(x)                    effects.py:342-385
  *         (cutoff_lfo: Filter.frequency driven per buffer by the voice's own Lfo)
  *   x   = fx[0](x), fx[1](x), ...                   when n_fx > 0: the stages in patch
- *         order, the Filter among them as KLMI_FX_FILTER (at most one Filter, one
- *         Tremolo and one Delay per chain); n_fx == 0 is the plain [Filter] chain
+ *         order, the Filter among them as KLMI_FX_FILTER (at most one stage of
+ *         each stateful kind per chain: Filter, Tremolo, Delay, Subsampler, RingModulator); n_fx == 0 is the plain [Filter] chain
  *   x   = has_reverb ? Reverb(x)                    effects.py:564-615
  *   bus = stereo ? StereoMixer : Mixer over voices  mixer.py:15-104
  */

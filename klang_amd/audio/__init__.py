@@ -5,8 +5,8 @@ from klang_amd.audio.signals import (FmOscillator, Lfo, Oscillator, Phasor, PwmO
 from klang_amd.audio.envelopes import ADSR, AR, D, R, Envelope
 from klang_amd.audio.filtering import (BackwardCombFilter, EchoFilter, Filter,
                                        ForwardCombFilter, Reverb)
-from klang_amd.audio.effects import (Delay, Gain, OctaveDistortion, TanhDistortion, Transformer,
-                                     Tremolo)
+from klang_amd.audio.effects import (Bitcrusher, Delay, Gain, OctaveDistortion, RingModulator,
+                                     Subsampler, TanhDistortion, Transformer, Tremolo)
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.voices import Voice
 from klang_amd.audio.synthesizer import (MonophonicSynthesizer, NoteScheduler,
@@ -18,4 +18,4 @@ __all__ = ['FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscillator', 'WAVE
            'BackwardCombFilter', 'EchoFilter', 'Filter', 'ForwardCombFilter', 'Reverb', 'Mixer',
            'StereoMixer', 'Voice', 'MonophonicSynthesizer', 'NoteScheduler', 'PolyphonicSynthesizer',
            'Synthesizer', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
-           'Transformer', 'Tremolo', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']
+           'Transformer', 'Tremolo', 'Bitcrusher', 'RingModulator', 'Subsampler', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']

@@ -1,7 +1,9 @@
 """Element-wise and delay effects (host side): ``Gain``, ``Transformer``,
-``TanhDistortion``, ``OctaveDistortion``, ``Tremolo``, ``Delay``.
+``TanhDistortion``, ``OctaveDistortion``, ``Tremolo``, ``Delay``, ``Subsampler``,
+``Bitcrusher``, ``RingModulator``.
 
-Mirrors klang/audio/effects.py:33-174, 452-561 and klang/ring_buffer.py:10-113.
+Mirrors klang/audio/effects.py:33-174, 388-449, 452-561, 618-662 and
+klang/ring_buffer.py:10-113.
 The ``update()`` methods are the ``backend='host'`` evaluation; inside a fused
 voice chain the same stages run on the device (mod_kernels.h).
 """
@@ -12,7 +14,7 @@ import numpy as np
 
 from klang_amd import native
 from klang_amd.audio.filtering import blend
-from klang_amd.audio.signals import PwmOscillator
+from klang_amd.audio.signals import Oscillator, PwmOscillator, square
 from klang_amd.block import Block
 from klang_amd.composite import Composite
 from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
@@ -21,7 +23,7 @@ from klang_amd.tempo import compute_duration
 from klang_amd.wiring import Input, Relay
 
 __all__ = ['Gain', 'Transformer', 'TanhDistortion', 'OctaveDistortion', 'Tremolo', 'Delay',
-           'DelayLine', 'low_pass_coefficients']
+           'DelayLine', 'Subsampler', 'Bitcrusher', 'RingModulator', 'low_pass_coefficients']
 
 
 @functools.lru_cache()
@@ -189,3 +191,66 @@ class Delay(Block):
         old = self.ring.peek()
         self.ring.extend(new + self.feedback * old)
         self.output.set_value(blend(new, old, self.drywet))
+
+
+class Subsampler(Block):
+    """Repeat every `factor`-th sample `factor` times (effects.py:388-417)."""
+
+    VALID_FACTORS = set(2 ** i for i in range(1, int(math.log2(BUFFER_SIZE))))
+
+    def __init__(self, factor):
+        assert factor in self.VALID_FACTORS
+        super().__init__(nInputs=1, nOutputs=1)
+        self.factor = factor
+
+    @staticmethod
+    def sub_sample(array, skip):
+        return np.repeat(array[..., ::skip], skip, axis=-1)
+
+    def update(self):
+        self.output.set_value(self.sub_sample(self.input.get_value(), self.factor))
+
+
+class Bitcrusher(Block):
+    """Drop the `nBits` lowest bits of the 16-bit sample (effects.py:420-449 with
+    wavfile.py:14-30): float -> int16 by truncation, arithmetic shifts, / 32768."""
+
+    def __init__(self, nBits=16):
+        assert 0 <= nBits < 16
+        super().__init__(nInputs=1, nOutputs=1)
+        self.nBits = nBits
+
+    @staticmethod
+    def bit_crush(samples, nBits):
+        ints = (np.iinfo(np.int16).max * np.asarray(samples)).astype(np.int16)
+        return ((ints >> nBits) << nBits) / abs(np.iinfo(np.int16).min)
+
+    def update(self):
+        self.output.set_value(self.bit_crush(self.input.get_value(), self.nBits))
+
+
+class RingModulator(Composite):
+    """Amplitude modulation by a sine whose frequency an Lfo sweeps
+    (effects.py:618-662): out = blend(x, sin-modulator * x, dryWet)."""
+
+    def __init__(self, frequency=500., rate=2., amount=20, wave_func=square, dryWet=1.):
+        super().__init__()
+        self.inputs = [Input(owner=self), Input(owner=self), Relay(owner=self),
+                       Input(owner=self), Input(owner=self)]
+        self.outputs = [Relay(owner=self)]
+        _, self.frequency, self.rate, self.amount, self.dryWet = self.inputs
+        self.frequency.set_value(frequency)
+        self.rate.set_value(rate)
+        self.amount.set_value(amount)
+        self.dryWet.set_value(dryWet)
+        self.lfo = Oscillator(wave_func=wave_func)
+        self.modulator = Oscillator()
+        self.rate.connect(self.lfo.frequency)
+
+    def update(self):
+        self.lfo.update()
+        freqs = self.frequency.value + self.amount.value * self.lfo.output.value
+        self.modulator.frequency.set_value(freqs)
+        self.modulator.update()
+        x = self.input.value
+        self.output.set_value(blend(x, self.modulator.output.value * x, self.dryWet.value))

@@ -58,7 +58,8 @@ struct BankView {
     int n_fx;
     unsigned char fx_kind[8];  // FxKind
     const double *fx_par;      // [8][kFxSlots][n] per-stage device parameters
-    double *fx_state;          // [8][2][n]: tremolo lfo phase, zi; delay position
+    double *fx_state;          // [8][2][n]: tremolo lfo phase, zi; delay position; ring modulator
+                               // lfo phase, modulator phase
     double *fx_ring;           // the delay stage's lines, [n][fx_ring_stride] (voice-major: ring
                                // positions differ per voice); slots [len, len+8) mirror [0, 8)
     int fx_ring_stride;
@@ -74,10 +75,12 @@ struct BankView {
     int32_t *current_pitch;     // [n] state: Voice.currentPitch
 };
 
-enum FxKind : int { FX_NONE = 0, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY };
+enum FxKind : int { FX_NONE = 0, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY,
+                    FX_SUBSAMPLE, FX_BITCRUSH, FX_RINGMOD };
 // device parameter rows per stage: GAIN gain | TRANSFORM scale, offset | TANH drive |
 // TREMOLO rate, depth, duty, b0, a1 (one-pole design done on the host, effects.py:124-125) |
-// DELAY length (samples), feedback, drywet
+// DELAY length (samples), feedback, drywet | SUBSAMPLE factor | BITCRUSH nBits |
+// RINGMOD frequency, rate, amount, dryWet, lfo wave
 constexpr int kFxSlots = 6;
 
 enum ModTarget : int { MT_NONE = 0, MT_FM = 1, MT_FREQUENCY = 2, MT_DUTY = 3 };

@@ -396,7 +396,7 @@ struct klmi_bank {
     DevBuf<int32_t> wave;
     DevBuf<uint32_t> env_flags;
     int f64_slots = 0;                   // rows of the float64 state slab
-    // effect stages (desc.n_fx > 0): parameters as the blocks take them [8][4][n] on the
+    // effect stages (desc.n_fx > 0): parameters as the blocks take them [8][KLMI_FX_PARAMS][n] on the
     // host, what the kernel needs [8][kFxSlots][n] on the device, the delay stage's rings
     std::vector<double> fx_raw;
     DevBuf<double> fx_par, fx_ring, fx_ring_backup;
@@ -582,7 +582,9 @@ static int upload_fx(klmi_bank *b, int stage, int first, int count)
     const size_t n = (size_t)b->n;
     const int kind = b->desc.fx[stage];
     std::vector<double> dev((size_t)kFxSlots * count, 0.);
-    auto raw = [&](int k, int i) { return b->fx_raw[((size_t)stage * 4 + k) * n + first + i]; };
+    auto raw = [&](int k, int i) {
+        return b->fx_raw[((size_t)stage * KLMI_FX_PARAMS + k) * n + first + i];
+    };
     for (int i = 0; i < count; ++i) {
         double d[kFxSlots] = {raw(0, i), raw(1, i), raw(2, i), raw(3, i), 0., 0.};
         if (kind == KLMI_FX_TREMOLO) {
@@ -597,6 +599,8 @@ static int upload_fx(klmi_bank *b, int stage, int first, int count)
             d[2] = duty, d[3] = lb[0], d[4] = la[1];  // rate, depth, duty, b0, a1
         } else if (kind == KLMI_FX_DELAY) {
             d[0] = (double)(int)(raw(0, i) * KLMI_SAMPLING_RATE);  // effects.py:155 length
+        } else if (kind == KLMI_FX_RINGMOD) {
+            d[4] = raw(4, i);  // frequency, rate, amount, dryWet, lfo wave
         }
         for (int k = 0; k < kFxSlots; ++k)
             dev[(size_t)k * count + i] = d[k];
@@ -618,7 +622,7 @@ static int ensure_fx_ring(klmi_bank *b)
     const size_t n = (size_t)b->n;
     int cap = 0;
     for (size_t v = 0; v < n; ++v)
-        cap = std::max(cap, (int)(b->fx_raw[((size_t)b->fx_delay_stage * 4) * n + v] *
+        cap = std::max(cap, (int)(b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + v] *
                                   KLMI_SAMPLING_RATE));
     if (cap == b->fx_ring_cap)
         return 0;
@@ -658,16 +662,17 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     if (desc->n_fx < 0 || desc->n_fx > KLMI_MAX_FX)
         return fail(KLMI_E_ARG, "klmi_bank_create: n_fx %d outside 0..%d", desc->n_fx, KLMI_MAX_FX);
     {
-        int seen[KLMI_FX_DELAY + 1] = {};
+        int seen[KLMI_FX_RINGMOD + 1] = {};
         for (int i = 0; i < desc->n_fx; ++i) {
-            if (desc->fx[i] < KLMI_FX_FILTER || desc->fx[i] > KLMI_FX_DELAY)
+            if (desc->fx[i] < KLMI_FX_FILTER || desc->fx[i] > KLMI_FX_RINGMOD)
                 return fail(KLMI_E_ARG, "klmi_bank_create: unknown effect kind %d at stage %d",
                             desc->fx[i], i);
             seen[desc->fx[i]]++;
         }
-        if (seen[KLMI_FX_FILTER] > 1 || seen[KLMI_FX_TREMOLO] > 1 || seen[KLMI_FX_DELAY] > 1)
-            return fail(KLMI_E_ARG, "klmi_bank_create: at most one Filter, one Tremolo and one "
-                                    "Delay stage per chain");
+        if (seen[KLMI_FX_FILTER] > 1 || seen[KLMI_FX_TREMOLO] > 1 || seen[KLMI_FX_DELAY] > 1 ||
+            seen[KLMI_FX_SUBSAMPLE] > 1 || seen[KLMI_FX_RINGMOD] > 1)
+            return fail(KLMI_E_ARG, "klmi_bank_create: at most one Filter, Tremolo, Delay, "
+                                    "Subsampler and RingModulator stage per chain");
         if (desc->n_fx && (seen[KLMI_FX_FILTER] != 0) != (desc->has_filter != 0))
             return fail(KLMI_E_ARG, "klmi_bank_create: has_filter and a KLMI_FX_FILTER stage go "
                                     "together");
@@ -774,13 +779,15 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     }
     if (desc->n_fx) {
         // the blocks' own defaults (effects.py:62, 89-90, 143, 473; Transformer: identity)
-        static const double defaults[KLMI_FX_DELAY + 1][4] = {
-            {0, 0, 0, 0}, {0, 0, 0, 0}, {1., 0, 0, 0}, {1., 0., 0, 0}, {1., 0, 0, 0},
-            {0, 0, 0, 0}, {3., .8, 1., .5}, {1., .1, .5, 0}};
-        b->fx_raw.assign((size_t)KLMI_MAX_FX * 4 * n, 0.);
+        // (effects.py:62, 89-90, 143, 473, 628-629; Subsampler / Bitcrusher have no defaults
+        // worth the name: factor 2, nBits 0)
+        static const double defaults[KLMI_FX_RINGMOD + 1][KLMI_FX_PARAMS] = {
+            {0}, {0}, {1.}, {1., 0.}, {1.}, {0}, {3., .8, 1., .5}, {1., .1, .5},
+            {2.}, {0.}, {500., 2., 20., 1., KLMI_WAVE_SQUARE}};
+        b->fx_raw.assign((size_t)KLMI_MAX_FX * KLMI_FX_PARAMS * n, 0.);
         for (int st = 0; st < desc->n_fx; ++st) {
-            for (int k = 0; k < 4; ++k)
-                std::fill_n(b->fx_raw.begin() + ((size_t)st * 4 + k) * n, n,
+            for (int k = 0; k < KLMI_FX_PARAMS; ++k)
+                std::fill_n(b->fx_raw.begin() + ((size_t)st * KLMI_FX_PARAMS + k) * n, n,
                             defaults[desc->fx[st]][k]);
             if (desc->fx[st] == KLMI_FX_DELAY)
                 b->fx_delay_stage = st;
@@ -880,7 +887,8 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
         return 0;
     hipStream_t st = b->ctx->stream;
     if (field >= KLMI_F_FX(0, 0) && field < KLMI_F_FX(KLMI_MAX_FX, 0)) {
-        const int stage = (field - KLMI_F_FX(0, 0)) / 4, k = (field - KLMI_F_FX(0, 0)) % 4;
+        const int stage = (field - KLMI_F_FX(0, 0)) / KLMI_FX_PARAMS;
+        const int k = (field - KLMI_F_FX(0, 0)) % KLMI_FX_PARAMS;
         if (stage >= b->desc.n_fx)
             return fail(KLMI_E_ARG, "klmi_bank_set_params: the chain has %d effect stage(s), "
                                     "stage %d addressed", b->desc.n_fx, stage);
@@ -893,7 +901,29 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
                                             "one buffer (%d samples)", host[i], KLMI_BUFFER_SIZE);
             }
         }
-        std::copy(host, host + count, b->fx_raw.begin() + ((size_t)stage * 4 + k) * b->n + first);
+        if (b->desc.fx[stage] == KLMI_FX_SUBSAMPLE && k == 0) {
+            for (int i = 0; i < count; ++i) {  // effects.py:392-400 VALID_FACTORS
+                const int f = (int)host[i];
+                if ((double)f != host[i] || f < 2 || f > KLMI_BUFFER_SIZE / 2 || (f & (f - 1)))
+                    return fail(KLMI_E_ARG, "klmi_bank_set_params: Subsampler factor %g is not a "
+                                            "power of 2 in 2..%d", host[i], KLMI_BUFFER_SIZE / 2);
+            }
+        }
+        if (b->desc.fx[stage] == KLMI_FX_BITCRUSH && k == 0) {
+            for (int i = 0; i < count; ++i)    // effects.py:431
+                if (!(host[i] >= 0. && host[i] < 16.) || host[i] != std::floor(host[i]))
+                    return fail(KLMI_E_ARG, "klmi_bank_set_params: Bitcrusher nBits %g outside 0..15",
+                                host[i]);
+        }
+        if (b->desc.fx[stage] == KLMI_FX_RINGMOD && k == 4) {
+            for (int i = 0; i < count; ++i)
+                if (!(host[i] >= 0. && host[i] <= (double)KLMI_WAVE_TRIANGLE) ||
+                    host[i] != std::floor(host[i]))
+                    return fail(KLMI_E_ARG, "klmi_bank_set_params: RingModulator Lfo wave id %g "
+                                            "(sine, square, sawtooth, triangle are 0..3)", host[i]);
+        }
+        std::copy(host, host + count,
+                  b->fx_raw.begin() + ((size_t)stage * KLMI_FX_PARAMS + k) * b->n + first);
         if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0)
             b->fx_ring_cap = 0;  // new lengths: the lines (and their mirror slots) start empty
         return upload_fx(b, stage, first, count);

@@ -154,13 +154,27 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     double lfo_ph = cutoff_lfo ? bk.lfo_phase[v] : 0.;
 
     // effect stages: at most one Tremolo and one Delay per chain, so their state is scalar
-    int trem_stage = -1, delay_stage = -1;
+    int trem_stage = -1, delay_stage = -1, ring_stage = -1;
     for (int s = 0; s < bk.n_fx; ++s) {
         if (bk.fx_kind[s] == FX_TREMOLO)
             trem_stage = s;
         if (bk.fx_kind[s] == FX_DELAY)
             delay_stage = s;
+        if (bk.fx_kind[s] == FX_RINGMOD)
+            ring_stage = s;
     }
+    // RingModulator (effects.py:618-662): its Lfo and its sine modulator
+    double ring_freq = 0., ring_rate = 0., ring_amount = 0., ring_dw = 0.;
+    double ring_lfo_phase = 0., ring_phase = 0.;
+    int ring_wave = 0;
+    if (ring_stage >= 0) {
+        const double *par = bk.fx_par + (size_t)(ring_stage * kFxSlots) * n + v;
+        ring_freq = par[0], ring_rate = par[n], ring_amount = par[2 * n], ring_dw = par[3 * n];
+        ring_wave = (int)par[4 * n];
+        ring_lfo_phase = bk.fx_state[(size_t)(2 * ring_stage) * n + v];
+        ring_phase = bk.fx_state[(size_t)(2 * ring_stage + 1) * n + v];
+    }
+    double held = 0.;   // Subsampler: the sample being repeated (at most one per chain)
     double trem_phase = 0., trem_z = 0.;
     if (trem_stage >= 0) {
         trem_phase = bk.fx_state[(size_t)(2 * trem_stage) * n + v];
@@ -285,6 +299,8 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         const double mod_start = mod_phase;
         double running = 0.;                        // np.cumsum(frequency) within this block
         const double trem_start = trem_phase;
+        const double ring_lfo_start = ring_lfo_phase, ring_start = ring_phase;
+        double ring_running = 0.;                   // np.cumsum of the modulator's frequencies
         // Wave-uniform: every remainder argument of this block is finite and below 1e9 in
         // magnitude, so the branch-free remainder applies (lane-divergent early-outs and
         // the library fallback cost far more than the operations they save).
@@ -293,7 +309,9 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             fabs(omega) * t_end + fabs(start) < 1e9 &&
             fabs(mod_omega) * t_end + fabs(mod_start) < 1e9 && fabs(mod_scale) < 1e8 &&
             (kTau * kDt) * kBlock * (fabs(mod_scale) + fabs(mod_offset)) + fabs(start) < 1e9 &&
-            fabs(kTau * trem_rate) * t_end + fabs(trem_start) < 1e9);
+            fabs(kTau * trem_rate) * t_end + fabs(trem_start) < 1e9 &&
+            fabs(kTau * ring_rate) * t_end + fabs(ring_lfo_start) < 1e9 &&
+            (kTau * kDt) * kBlock * (fabs(ring_freq) + fabs(ring_amount)) + fabs(ring_start) < 1e9);
 
         // Eight oscillator samples (with the modulator's): per sample the reference's
         // operations in the reference's order, but staged over the group so that every
@@ -483,6 +501,47 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                                 x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
                             break;
                         }
+                        case FX_SUBSAMPLE: {  // effects.py:400-415: np.repeat(x[::skip], skip)
+                            const int mask = (int)p0 - 1;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                held = ((c * CH + i8 + j) & mask) == 0 ? x[j] : held;
+                                x[j] = held;
+                            }
+                            break;
+                        }
+                        case FX_BITCRUSH: {   // effects.py:434-447, wavfile.py:14-30
+                            const int bits = (int)p0;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int q = (int)(short)(int)(32767. * x[j]);  // astype(int16)
+                                x[j] = (double)(int)(short)((q >> bits) << bits) * (1. / 32768.);
+                            }
+                            break;
+                        }
+                        case FX_RINGMOD: {    // effects.py:650-662
+                            double f[8], ph[8], am[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)     // the Lfo: Oscillator.sample, scalar rate
+                                ph[j] = bounded_block
+                                            ? np_mod_tau_bounded(kTau * ring_rate * tt.t[j] + ring_lfo_start)
+                                            : np_mod_tau(kTau * ring_rate * tt.t[j] + ring_lfo_start);
+                            wave_block<true, false>(-1, ring_wave, ph, kPi, f);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {   // modulator: array branch of sample_phase
+                                const double fj = ring_freq + ring_amount * f[j];
+                                const bool first_sample = c == 0 && i8 == 0 && j == 0;
+                                const double arg = first_sample ? ring_start
+                                                                : (kTau * kDt) * ring_running + ring_start;
+                                ph[j] = bounded_block ? np_mod_tau_bounded(arg) : np_mod_tau(arg);
+                                ring_running = first_sample ? fj : ring_running + fj;
+                            }
+                            wave_block<true, false>(W_SINE, W_SINE, ph, kPi, am);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)     // math.py:68-75 blend(x, am * x, dryWet)
+                                x[j] = (1. - ring_dw) * x[j] + ring_dw * (am[j] * x[j]);
+                            break;
+                        }
                         default:
                             break;
                         }
@@ -499,6 +558,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             trem_phase = np_mod_tau(kTau * trem_rate * c_time[kBlock] + trem_start);
         if (delay_stage >= 0)
             delay_pos = (delay_pos + kBlock) % delay_len;
+        if (ring_stage >= 0) {
+            ring_lfo_phase = np_mod_tau(kTau * ring_rate * c_time[kBlock] + ring_lfo_start);
+            ring_phase = np_mod_tau((kTau * kDt) * ring_running + ring_start);
+        }
         if (target != MT_NONE)
             mod_phase = np_mod_tau(mod_omega * c_time[kBlock] + mod_start);
         if (wave_id != W_ONE && wave_id != W_EXTERNAL) {
@@ -536,6 +599,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         }
         if (delay_stage >= 0)
             bk.fx_state[(size_t)(2 * delay_stage) * n + v] = (double)delay_pos;
+        if (ring_stage >= 0) {
+            bk.fx_state[(size_t)(2 * ring_stage) * n + v] = ring_lfo_phase;
+            bk.fx_state[(size_t)(2 * ring_stage + 1) * n + v] = ring_phase;
+        }
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
         if (poly > 0) {
             bk.nt_cursor[v] = nt_i - bk.nt_offset[v / poly];

@@ -6,9 +6,11 @@ klang/execution.py:37-58 in the reference).  In that order every ``Mixer`` /
 ``StereoMixer`` whose inputs are all *voice chains* of one shape
 
     Voice(Oscillator|PwmOscillator|FmOscillator, ADSR|AR|D|R)  or a bare oscillator
-        [ | Filter | Gain | Transformer | TanhDistortion | OctaveDistortion | Tremolo | Delay ]*
+        [ | Filter | Gain | Transformer | TanhDistortion | OctaveDistortion | Tremolo | Delay
+          | Subsampler | Bitcrusher | RingModulator ]*
         [ | Reverb ]   ->  mixer input
-    (effect stages in any order, at most one Filter, one Tremolo and one Delay per chain)
+    (effect stages in any order, at most one of each stateful kind per chain: Filter, Tremolo,
+    Delay, Subsampler, RingModulator)
 
 with, optionally, one modulation source per voice:
 ``Lfo(shape=1) | filter.frequency``, ``Lfo(shape=256) | oscillator.frequency``,
@@ -32,8 +34,8 @@ from fractions import Fraction
 import numpy as np
 
 from klang_amd import native
-from klang_amd.audio.effects import (Delay, Gain, OctaveDistortion, TanhDistortion, Transformer,
-                                     Tremolo)
+from klang_amd.audio.effects import (Bitcrusher, Delay, Gain, OctaveDistortion, RingModulator,
+                                     Subsampler, TanhDistortion, Transformer, Tremolo)
 from klang_amd.audio.envelopes import EnvelopeBase
 from klang_amd.audio.filtering import BackwardCombFilter, Filter, Reverb
 from klang_amd.audio.mixers import Mixer, StereoMixer
@@ -49,7 +51,10 @@ from klang_amd.tempo import compute_rate
 
 EFFECT_KINDS = {Filter: native.FX_FILTER, Gain: native.FX_GAIN, Transformer: native.FX_TRANSFORM,
                 TanhDistortion: native.FX_TANH, OctaveDistortion: native.FX_OCTAVE,
-                Tremolo: native.FX_TREMOLO, Delay: native.FX_DELAY}
+                Tremolo: native.FX_TREMOLO, Delay: native.FX_DELAY,
+                Subsampler: native.FX_SUBSAMPLE, Bitcrusher: native.FX_BITCRUSH,
+                RingModulator: native.FX_RINGMOD}
+ONE_PER_CHAIN = (Filter, Tremolo, Delay, Subsampler, RingModulator)   # stateful stages
 HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer, Synthesizer) + tuple(
     t for t in EFFECT_KINDS if t is not Filter)
 
@@ -74,14 +79,18 @@ class Chain:
 
     def _check_stage(self, stage):
         kind = type(stage)
-        if sum(type(st) is kind for st in self.stages) and kind in (Filter, Tremolo, Delay):
+        if sum(type(st) is kind for st in self.stages) and kind in ONE_PER_CHAIN:
             raise NotFusable('%s: one %s per chain runs on the device' % (stage, kind.__name__))
         if kind is Filter:
             if stage.frequency.connected:
                 self.cutoff_lfo = self._private_lfo(stage.frequency, SCALAR, '%s.frequency' % stage)
             self.filter = stage
-        elif any(i.connected for i in stage.inputs[1:]):
+        elif any(i.connected for i in stage.inputs if i is not stage.input):
             raise NotFusable('%s: its parameter inputs are patched (modulated)' % stage)
+        if kind is RingModulator:
+            if stage.lfo.wave_func not in WAVE_IDS or WAVE_IDS[stage.lfo.wave_func] > native.WAVE_TRIANGLE:
+                raise NotFusable('%s: Lfo wave function %r has no device twin'
+                                 % (stage, stage.lfo.wave_func))
         if kind is Delay:
             if stage.ring.length < BUFFER_SIZE:
                 raise NotFusable('%s: delay lines shorter than one buffer are not fused' % stage)
@@ -297,6 +306,15 @@ class GpuVoiceBank(Block):
         if isinstance(stage, Delay):
             return (float(stage.time), float(stage.feedback), float(stage.drywet)), \
                    (float(stage.ring.pos),)
+        if isinstance(stage, Subsampler):
+            return (float(stage.factor),), ()
+        if isinstance(stage, Bitcrusher):
+            return (float(stage.nBits),), ()
+        if isinstance(stage, RingModulator):
+            return ((float(stage.frequency.value), float(compute_rate(stage.rate.value)),
+                     float(stage.amount.value), float(stage.dryWet.value),
+                     float(WAVE_IDS[stage.lfo.wave_func])),
+                    (float(stage.lfo.currentPhase), float(stage.modulator.currentPhase)))
         return (), ()
 
     def _upload_stage(self, s, force=False):
@@ -415,6 +433,11 @@ class GpuVoiceBank(Block):
             elif kind == F.FX_DELAY:
                 for c, p in zip(self.chains, bank.get_state(F.F_FX_STATE(s, 0))):
                     c.stages[s].ring.pos = int(p)
+            elif kind == F.FX_RINGMOD:
+                lfo, mod = bank.get_state(F.F_FX_STATE(s, 0)), bank.get_state(F.F_FX_STATE(s, 1))
+                for i, c in enumerate(self.chains):
+                    c.stages[s].lfo.currentPhase = float(lfo[i])
+                    c.stages[s].modulator.currentPhase = float(mod[i])
         if self.chains[0].voice is not None:
             value, stage = bank.get_state(F.F_ENV_VALUE), bank.get_state(F.F_ENV_STAGE)
             enabled = bank.get_state(F.F_ENV_ENABLED)

@@ -29,13 +29,15 @@ F_PHASE, F_ENV_VALUE, F_ENV_STAGE, F_ENV_ENABLED, F_Z0, F_Z1, F_LFO_PHASE, F_MOD
 F_CURRENT_PITCH, F_ROUND_ROBIN = 40, 41
 MOD_NONE, MOD_FM, MOD_FREQUENCY, MOD_DUTY = range(4)   # klmi_mod_target
 # klmi_fx_kind, KLMI_F_FX / KLMI_F_FX_STATE
-FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY = range(8)
+FX_NONE, FX_FILTER, FX_GAIN, FX_TRANSFORM, FX_TANH, FX_OCTAVE, FX_TREMOLO, FX_DELAY, \
+    FX_SUBSAMPLE, FX_BITCRUSH, FX_RINGMOD = range(11)
+FX_PARAMS = 8
 MAX_FX = 8
 
 
 def F_FX(stage, k):
-    """Field id of parameter k (0..3) of effect stage `stage`."""
-    return 64 + 4 * stage + k
+    """Field id of parameter k (0..7) of effect stage `stage`."""
+    return 64 + FX_PARAMS * stage + k
 
 
 def F_FX_STATE(stage, k):

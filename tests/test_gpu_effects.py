@@ -37,6 +37,14 @@ def saw_bank(hip, ctx, stages, n=1, **kw):
     ('tremolo_square', ('FX_TREMOLO', 7., .5, 0., .5), 30, 0.),
     ('delay', ('FX_DELAY', .01, .6, .4), 40, 0.),
     ('delay_long', ('FX_DELAY', .0437, .9, .5), 40, 0.),
+    ('subsample_4', ('FX_SUBSAMPLE', 4), 6, 0.),
+    ('subsample_64', ('FX_SUBSAMPLE', 64), 6, 0.),
+    ('bitcrush_5', ('FX_BITCRUSH', 5), 12, 0.),
+    ('bitcrush_0', ('FX_BITCRUSH', 0), 6, 0.),
+    ('bitcrush_13', ('FX_BITCRUSH', 13), 6, 0.),
+    ('ringmod_square', ('FX_RINGMOD', 500., 2., 20., .8, 1), 40, 1e-13),   # sine AM: libm ulps
+    ('ringmod_sine', ('FX_RINGMOD', 500., 2., 20., .8, 0), 40, 1e-10),     # ... inside the cumsum
+    ('ringmod_triangle', ('FX_RINGMOD', 500., 2., 20., .8, 3), 40, 1e-13),
 ])
 def test_effect_stage_vs_reference(hip, ctx, golden, key, stage, n_blocks, tol):
     want = golden('effects')[key]
@@ -56,6 +64,10 @@ def test_effect_stage_vs_reference(hip, ctx, golden, key, stage, n_blocks, tol):
         assert bank.get_state(hip.F_FX_STATE(0, 1))[0] == final[1]
     if key == 'delay':
         assert bank.get_state(hip.F_FX_STATE(0, 0))[0] == golden('effects')['delay_final_pos_length'][0]
+    if key.startswith('ringmod'):
+        final = golden('effects')[key + '_final']
+        assert abs(bank.get_state(hip.F_FX_STATE(0, 0))[0] - final[0]) <= 1e-12
+        assert abs(bank.get_state(hip.F_FX_STATE(0, 1))[0] - final[1]) <= 1e-9
 
 
 def test_effect_chain_after_a_voice_vs_reference(hip, ctx, golden):
@@ -106,6 +118,51 @@ def test_effect_chains_vs_oracle_many_voices(hip, ctx, oracle):
     np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
 
 
+def test_crusher_and_ring_modulator_vs_oracle_many_voices(hip, ctx, oracle):
+    """600 voices through Gain -> Bitcrusher -> RingModulator(non-sine Lfo) -> Subsampler ->
+    Filter with per-voice parameters; Gain up to 1.5 so that the int16 wrap of the crusher
+    is exercised.  The modulator's sine makes it 'a few ulp', not bit-exact."""
+    n, nb = 600, 10
+    rng = np.random.default_rng(33)
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=5)
+    stages = [(hip.FX_GAIN, 1.5 * rng.random(n)), (hip.FX_BITCRUSH, rng.integers(0, 16, n)),
+              (hip.FX_RINGMOD, 100. + 900. * rng.random(n), .5 + 8. * rng.random(n),
+               50. * rng.random(n), rng.random(n), rng.integers(1, 4, n)),
+              (hip.FX_SUBSAMPLE, 2 ** rng.integers(1, 8, n)), (hip.FX_FILTER,)]
+    table, grid = library_table(hip)
+    from tests.helpers import oracle_bank_from_patch
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.set_effects(stages)
+    hb = hip.Bank(ctx, n, has_env=True, has_filter=True, effects=[s[0] for s in stages])
+    hb.load_patch(patch)
+    for s, st in enumerate(stages):
+        for k, p in enumerate(st[1:]):
+            hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+    got = hb.render_voices(nb, f64=True)
+    assert np.abs(got - want_voices).max() <= 1e-12
+    mix = np.concatenate([hb.render(4), hb.render(6)])
+    assert np.abs(mix[:, 0, :] - want_mix[:, 0, :]).max() <= 1e-6
+    np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(2, 0)), ob.fx_state[2, 0])
+    assert np.abs(hb.get_state(hip.F_FX_STATE(2, 1)) - ob.fx_state[2, 1]).max() <= 1e-9
+
+
+def test_crusher_without_transcendentals_is_bit_exact(hip, ctx, oracle):
+    """Gain -> Bitcrusher -> Subsampler on saws: integer work in between, exact."""
+    n, nb = 300, 6
+    rng = np.random.default_rng(34)
+    stages = [(hip.FX_GAIN, 1.4 * rng.random(n)), (hip.FX_BITCRUSH, rng.integers(0, 16, n)),
+              (hip.FX_SUBSAMPLE, 2 ** rng.integers(1, 8, n))]
+    ob = oracle.OracleBank(n, False, False, False)
+    ob.wave[:] = oracle.WAVE_IDS['sawtooth']
+    ob.frequency[:] = 50. + 2000. * rng.random(n)
+    ob.set_effects(stages)
+    hb = saw_bank(hip, ctx, stages, n=n)
+    hb.set(hip.F_FREQUENCY, ob.frequency)
+    _, want = ob.render(nb, want_voices=True)
+    np.testing.assert_array_equal(hb.render_voices(nb, f64=True), want)
+
+
 def test_effect_argument_errors(hip, ctx):
     with pytest.raises(hip.NativeError):
         hip.Bank(ctx, 2, effects=[hip.FX_DELAY, hip.FX_DELAY])          # one Delay per chain
@@ -114,7 +171,16 @@ def test_effect_argument_errors(hip, ctx):
     with pytest.raises(hip.NativeError):
         hip.Bank(ctx, 2, effects=[hip.FX_FILTER])                       # has_filter missing
     with pytest.raises(hip.NativeError):
-        hip.Bank(ctx, 2, effects=[9])
+        hip.Bank(ctx, 2, effects=[11])
+    with pytest.raises(hip.NativeError):
+        hip.Bank(ctx, 2, effects=[hip.FX_SUBSAMPLE, hip.FX_SUBSAMPLE])
+    odd = hip.Bank(ctx, 2, effects=[hip.FX_SUBSAMPLE, hip.FX_BITCRUSH, hip.FX_RINGMOD])
+    for field, bad in ((hip.F_FX(0, 0), [3., 2.]), (hip.F_FX(0, 0), [256., 2.]),
+                       (hip.F_FX(1, 0), [16., 2.]), (hip.F_FX(1, 0), [-1., 2.]),
+                       (hip.F_FX(2, 4), [4., 0.])):
+        with pytest.raises(hip.NativeError):
+            odd.set(field, bad)
+    odd.close()
     bank = hip.Bank(ctx, 2, effects=[hip.FX_GAIN, hip.FX_DELAY])
     with pytest.raises(hip.NativeError) as e:
         bank.set(hip.F_FX(1, 0), [2.5, 1.])

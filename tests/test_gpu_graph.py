@@ -229,10 +229,21 @@ def _effect_patches():
                       | Transformer(.5, .1 * k) | Filter(frequency=800. + 300 * k))
         return mixer | Dac()
 
-    return dict(arpeggiator_like=arpeggiator_like, tremolo_chain=tremolo_chain, shaping=shaping)
+    def lofi():               # Bitcrusher / Subsampler / RingModulator in voice chains
+        from klang_amd.audio import Bitcrusher, RingModulator, Subsampler
+        mixer = Mixer()
+        for k in range(3):
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+            voice.input.push(Note(0, .9, frequency=110. * (k + 1)))
+            mixer += (voice | RingModulator(frequency=300. + 100 * k, rate=3., amount=30., dryWet=.7)
+                      | Bitcrusher(4 + k) | Subsampler(2 ** (k + 1)))
+        return mixer | Dac()
+
+    return dict(arpeggiator_like=arpeggiator_like, tremolo_chain=tremolo_chain, shaping=shaping,
+                lofi=lofi)
 
 
-@pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping'])
+@pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping', 'lofi'])
 def test_effect_patches_match_the_host_evaluation(hip, name):
     build = _effect_patches()[name]
     order, banks = fusion.compile_order(determine_execution_order([build()]))

@@ -285,6 +285,20 @@ def test_effect_blocks_match_reference_fixtures(golden):
     _run_effect(lambda: Delay(time=.0437, feedback=.9, drywet=.5), 40, 'delay_long', golden)
     with pytest.raises(ValueError):
         Delay(time=2.5)
+    from klang_amd.audio import Bitcrusher, RingModulator, Subsampler, sine, square, triangle
+    _run_effect(lambda: Subsampler(4), 6, 'subsample_4', golden)
+    _run_effect(lambda: Subsampler(64), 6, 'subsample_64', golden)
+    for bits in (5, 0, 13):
+        _run_effect(lambda: Bitcrusher(bits), 12 if bits == 5 else 6, 'bitcrush_%d' % bits, golden)
+    for wname, wave in (('square', square), ('sine', sine), ('triangle', triangle)):
+        rm = _run_effect(lambda: RingModulator(frequency=500., rate=2., amount=20., wave_func=wave,
+                                               dryWet=.8), 40, 'ringmod_' + wname, golden)
+        final = golden('effects')['ringmod_%s_final' % wname]
+        assert [rm.lfo.currentPhase, rm.modulator.currentPhase] == list(final)
+    with pytest.raises(AssertionError):
+        Subsampler(3)
+    with pytest.raises(AssertionError):
+        Bitcrusher(16)
 
 
 # ---- synthesizers (synthesizer.py:87-219) ------------------------------------------
