@@ -21,13 +21,13 @@
 
 namespace klmi {
 
-// Eight wave-function values with the dispatch OUTSIDE the sample loop: `sel` is the
+// G wave-function values with the dispatch OUTSIDE the sample loop: `sel` is the
 // wavefront's common wave id (scalar: one jump per group, straight-line code per case)
 // or -1, in which case every lane switches on its own `lane_wave`.
 // WRAPPED: 0 <= p < TAU (a wrapped phase); otherwise any finite phase (FM).
-template <bool WRAPPED, bool BD>
-__device__ __forceinline__ void wave_block(int sel, int lane_wave, const double (&p)[8],
-                                           double duty_edge, double (&out)[8])
+template <bool WRAPPED, bool BD, int G>
+__device__ __forceinline__ void wave_block(int sel, int lane_wave, const double (&p)[G],
+                                           double duty_edge, double (&out)[G])
 {
     auto eval = [&](int w, double ph) {
         if constexpr (WRAPPED)
@@ -38,32 +38,32 @@ __device__ __forceinline__ void wave_block(int sel, int lane_wave, const double 
     switch (sel) {
     case W_SINE:
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < G; ++j)
             out[j] = eval(W_SINE, p[j]);
         break;
     case W_SQUARE:
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < G; ++j)
             out[j] = eval(W_SQUARE, p[j]);
         break;
     case W_SAWTOOTH:
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < G; ++j)
             out[j] = eval(W_SAWTOOTH, p[j]);
         break;
     case W_TRIANGLE:
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < G; ++j)
             out[j] = eval(W_TRIANGLE, p[j]);
         break;
     case W_PWM:
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < G; ++j)
             out[j] = eval(W_PWM, p[j]);
         break;
     default:
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < G; ++j)
             out[j] = eval(lane_wave, p[j]);
         break;
     }
@@ -74,7 +74,25 @@ struct __attribute__((packed, aligned(8))) Double2U {
     double a, b;
 };
 
-template <int MODE>
+// G consecutive time points of a block (G = 4 or 8)
+template <int G> struct TimeGroup {
+    double t[G];
+};
+template <int G>
+__device__ __forceinline__ TimeGroup<G> load_times(const double *times, int i)
+{
+    TimeGroup<G> r;   // wave-uniform index: one scalar load of G doubles
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        r.t[j] = times[i + j];
+    return r;
+}
+
+// HAS_FX: the chain has effect stages (bk.n_fx > 0).  Without them all stage code and
+// state is compiled out (232 VGPRs, nothing spilled).  With them the stage program's state
+// fills the register file (256 VGPRs + AGPR copies); groups of 4 instead of 8 were measured
+// slower (per-group dispatch), so only rarely used parameters are fetched where used.
+template <int MODE, bool HAS_FX>
 __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_env, int has_filter,
                                                            int first, int count, int block_base,
                                                            uint32_t clock_base, int n_blocks,
@@ -88,6 +106,9 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     constexpr int NCHUNK = kBlock / CH;
     constexpr int PLANES = TT::planes;
     constexpr bool MIX = (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
+    constexpr int G = 8;
+    using TimeG = TimeGroup<G>;
+    const int n_fx = HAS_FX ? bk.n_fx : 0;
 
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -155,7 +176,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
 
     // effect stages: at most one Tremolo and one Delay per chain, so their state is scalar
     int trem_stage = -1, delay_stage = -1, ring_stage = -1;
-    for (int s = 0; s < bk.n_fx; ++s) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {   // constant indices: the descriptor stays in scalar registers
+        if (s >= n_fx)
+            break;
         if (bk.fx_kind[s] == FX_TREMOLO)
             trem_stage = s;
         if (bk.fx_kind[s] == FX_DELAY)
@@ -195,15 +219,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         delay_len = (int)par[0];
         delay_fb = par[n], delay_dw = par[2 * n];
     }
-    double fx_p0[8], fx_p1[8];   // first two parameters of every stage
+    double fx_p0[8];   // first parameter of every stage (a second one is fetched where used)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        fx_p0[s] = fx_p1[s] = 0.;
-        if (s < bk.n_fx) {
-            fx_p0[s] = bk.fx_par[(size_t)(s * kFxSlots) * n + v];
-            fx_p1[s] = bk.fx_par[(size_t)(s * kFxSlots + 1) * n + v];
-        }
-    }
+    for (int s = 0; s < 8; ++s)
+        fx_p0[s] = s < n_fx ? bk.fx_par[(size_t)(s * kFxSlots) * n + v] : 0.;
 
     double gl = 0., gr = 0.;
     if (MIX) {
@@ -316,36 +335,36 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         // Eight oscillator samples (with the modulator's): per sample the reference's
         // operations in the reference's order, but staged over the group so that every
         // dispatch (target, wave functions) happens once per group, not once per sample.
-        auto osc_group = [&](auto bounded, const Time8 &tt, bool block_start, int sample0,
-                             double (&x)[8]) {
+        auto osc_group = [&](auto bounded, const TimeG &tt, bool block_start, int sample0,
+                             double (&x)[G]) {
             constexpr bool BD = decltype(bounded)::value;
-            double m[8], p[8];
+            double m[G], p[G];
             if (target != MT_NONE) {   // Oscillator.sample / Lfo.sample with shape 256
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     p[j] = np_mod_tau_sel<BD>(mod_omega * tt.t[j] + mod_start);
-                wave_block<true, BD>(uniform_mod_wave, mod_wave, p, kPi, m);
+                wave_block<true, BD, G>(uniform_mod_wave, mod_wave, p, kPi, m);
                 if (target != MT_FM) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < G; ++j)
                         m[j] = mod_scale * m[j] + mod_offset;
                 }
             }
             if (uniform_wave == W_ONE) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     x[j] = 1.;
                 return;
             }
             if (uniform_wave == W_EXTERNAL) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     x[j] = bk.ext_input[(size_t)(block_base * kBlock + sample0 + j) * n + v];
                 return;
             }
             if (target == MT_FREQUENCY) {   // oscillators.py:61-64, sequential running sum
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < G; ++j) {
                     const bool first_sample = block_start && j == 0;
                     p[j] = first_sample ? np_mod_tau_sel<BD>(start)
                                         : np_mod_tau_sel<BD>((kTau * kDt) * running + start);
@@ -353,24 +372,24 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     p[j] = np_mod_tau_sel<BD>(omega * tt.t[j] + start);
             }
             if (target == MT_FM) {          // oscillators.py:220: any phase
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     p[j] = p[j] + mod_scale * m[j];
-                wave_block<false, BD>(uniform_wave, wave_id, p, duty_edge, x);
+                wave_block<false, BD, G>(uniform_wave, wave_id, p, duty_edge, x);
             } else if (target == MT_DUTY) { // oscillators.py:259-260
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     x[j] = (p[j] < kTau * m[j]) ? 1. : -1.;
             } else {
-                wave_block<true, BD>(uniform_wave, wave_id, p, duty_edge, x);
+                wave_block<true, BD, G>(uniform_wave, wave_id, p, duty_edge, x);
             }
             if (uniform_wave < 0) {         // mixed wavefront: constant and external lanes
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < G; ++j) {
                     if (wave_id == W_ONE)
                         x[j] = 1.;
                     else if (wave_id == W_EXTERNAL)
@@ -381,80 +400,82 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
 
         for (int c = 0; c < NCHUNK; ++c) {
             const int s0 = b * kBlock + c * CH;
-            const Time8 *times = reinterpret_cast<const Time8 *>(c_time) + ((c * CH) >> 3);
-            // Eight samples per group: one scalar load of the time points, stage parameters
-            // from registers, and the eight delayed samples of a Delay stage fetched together
-            // (the line is at least one buffer long, so they never depend on this block's
-            // writes).  Arithmetic per sample is exactly the per-sample reference order.
-            for (int i8 = 0; i8 < CH; i8 += 8) {
-                const Time8 tt = times[i8 >> 3];
-                double x[8];
+            const double *times = c_time + c * CH;
+            // G samples per group: one scalar load of the time points, stage parameters from
+            // registers, and the G delayed samples of a Delay stage fetched together (the line
+            // is at least one buffer long, so they never depend on this block's writes).
+            // Arithmetic per sample is exactly the per-sample reference order.
+            for (int i8 = 0; i8 < CH; i8 += G) {
+                const TimeG tt = load_times<G>(times, i8);
+                double x[G];
                 // -- oscillator and its modulator ---------------------------------------
                 if (bounded_block)
                     osc_group(std::true_type{}, tt, c == 0 && i8 == 0, s0 + i8, x);
                 else
                     osc_group(std::false_type{}, tt, c == 0 && i8 == 0, s0 + i8, x);
-                // -- envelope: speculate "no stage switch in these 8" (monotone recurrence,
+                // -- envelope: speculate "no stage switch in these G" (monotone recurrence,
                 // see voice_kernel); on a hit in any lane the exact state machine runs
                 if (has_env) {
-                    double e[8];
+                    double e[G];
                     double vv = es.value;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < G; ++j) {
                         vv = es.base + vv * es.coef;
                         e[j] = vv;
                     }
                     if (__builtin_amdgcn_ballot_w64(es.reached(vv)) != 0) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
+                        for (int j = 0; j < G; ++j)
                             e[j] = es.step(ep);
                     } else {
                         es.value = vv;
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < G; ++j)
                         x[j] = amp * x[j] * e[j];
                 }
                 // -- stages -----------------------------------------------------------------
-                if (bk.n_fx == 0) {
+                if (!HAS_FX) {
                     if (has_filter) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
+                        for (int j = 0; j < G; ++j)
                             x[j] = bq.step(x[j]);
                     }
                 } else {
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {   // wave-uniform program, parameters in registers
-                        const double p0 = fx_p0[s], p1 = fx_p1[s];
-                        switch (s < bk.n_fx ? (int)bk.fx_kind[s] : (int)FX_NONE) {
+                        const double p0 = fx_p0[s];
+                        switch (s < n_fx ? (int)bk.fx_kind[s] : (int)FX_NONE) {
                         case FX_FILTER:
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int j = 0; j < G; ++j)
                                 x[j] = bq.step(x[j]);
                             break;
                         case FX_GAIN:       // effects.py:67-70
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int j = 0; j < G; ++j)
                                 x[j] = p0 * x[j];
                             break;
-                        case FX_TRANSFORM:  // effects.py:558-561
+                        case FX_TRANSFORM: {  // effects.py:558-561
+                            const double p1 = bk.fx_par[(size_t)(s * kFxSlots + 1) * n + v];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int j = 0; j < G; ++j)
                                 x[j] = p0 * x[j] + p1;
                             break;
+                        }
                         case FX_TANH:       // effects.py:480-483
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int j = 0; j < G; ++j)
                                 x[j] = tanh(p0 * x[j]);
                             break;
                         case FX_OCTAVE:     // effects.py:460-462
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int j = 0; j < G; ++j)
                                 x[j] = 2. * (x[j] * x[j]) - 1.;
                             break;
                         case FX_TREMOLO:    // effects.py:117-133
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
+                            for (int j = 0; j < G; ++j) {
                                 const double pa = kTau * trem_rate * tt.t[j] + trem_start;
                                 const double p = bounded_block ? np_mod_tau_bounded(pa) : np_mod_tau(pa);
                                 const double pwm = (p < kTau * trem_duty) ? 1. : -1.;
@@ -473,21 +494,21 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             int idx0 = delay_pos + c * CH + i8;
                             idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
                             double *line = delay_line + idx0;
-                            double w[8];
+                            double w[G];
 #pragma unroll
-                            for (int j = 0; j < 8; j += 2) {
+                            for (int j = 0; j < G; j += 2) {
                                 const Double2U old = reinterpret_cast<const Double2U *>(line)[j >> 1];
                                 w[j] = x[j] + delay_fb * old.a;
                                 w[j + 1] = x[j + 1] + delay_fb * old.b;
                             }
                             if (live) {
 #pragma unroll
-                                for (int j = 0; j < 8; j += 2)
+                                for (int j = 0; j < G; j += 2)
                                     reinterpret_cast<Double2U *>(line)[j >> 1] = Double2U{w[j], w[j + 1]};
                                 // keep slots and mirror in step where the 8 touch either end
-                                if (idx0 < 8 || idx0 + 8 > delay_len) {
+                                if (idx0 < 8 || idx0 + G > delay_len) {
 #pragma unroll
-                                    for (int j = 0; j < 8; ++j) {
+                                    for (int j = 0; j < G; ++j) {
                                         const int idx = idx0 + j;
                                         if (idx >= delay_len)
                                             delay_line[idx - delay_len] = w[j];
@@ -497,14 +518,14 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                                 }
                             }
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
+                            for (int j = 0; j < G; ++j)
                                 x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
                             break;
                         }
                         case FX_SUBSAMPLE: {  // effects.py:400-415: np.repeat(x[::skip], skip)
                             const int mask = (int)p0 - 1;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
+                            for (int j = 0; j < G; ++j) {
                                 held = ((c * CH + i8 + j) & mask) == 0 ? x[j] : held;
                                 x[j] = held;
                             }
@@ -513,22 +534,22 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                         case FX_BITCRUSH: {   // effects.py:434-447, wavfile.py:14-30
                             const int bits = (int)p0;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
+                            for (int j = 0; j < G; ++j) {
                                 const int q = (int)(short)(int)(32767. * x[j]);  // astype(int16)
                                 x[j] = (double)(int)(short)((q >> bits) << bits) * (1. / 32768.);
                             }
                             break;
                         }
                         case FX_RINGMOD: {    // effects.py:650-662
-                            double f[8], ph[8], am[8];
+                            double f[G], ph[G], am[G];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)     // the Lfo: Oscillator.sample, scalar rate
+                            for (int j = 0; j < G; ++j)     // the Lfo: Oscillator.sample, scalar rate
                                 ph[j] = bounded_block
                                             ? np_mod_tau_bounded(kTau * ring_rate * tt.t[j] + ring_lfo_start)
                                             : np_mod_tau(kTau * ring_rate * tt.t[j] + ring_lfo_start);
-                            wave_block<true, false>(-1, ring_wave, ph, kPi, f);
+                            wave_block<true, false, G>(-1, ring_wave, ph, kPi, f);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {   // modulator: array branch of sample_phase
+                            for (int j = 0; j < G; ++j) {   // modulator: array branch of sample_phase
                                 const double fj = ring_freq + ring_amount * f[j];
                                 const bool first_sample = c == 0 && i8 == 0 && j == 0;
                                 const double arg = first_sample ? ring_start
@@ -536,9 +557,9 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                                 ph[j] = bounded_block ? np_mod_tau_bounded(arg) : np_mod_tau(arg);
                                 ring_running = first_sample ? fj : ring_running + fj;
                             }
-                            wave_block<true, false>(W_SINE, W_SINE, ph, kPi, am);
+                            wave_block<true, false, G>(W_SINE, W_SINE, ph, kPi, am);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)     // math.py:68-75 blend(x, am * x, dryWet)
+                            for (int j = 0; j < G; ++j)     // math.py:68-75 blend(x, am * x, dryWet)
                                 x[j] = (1. - ring_dw) * x[j] + ring_dw * (am[j] * x[j]);
                             break;
                         }
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < G; ++j)
                     emit_sample<MODE>(tile, i8 + j, lane, x[j], gl, gr, live, out, s0, count, local);
             }
             flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);

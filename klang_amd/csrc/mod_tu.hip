@@ -9,7 +9,7 @@ hipError_t upload_time_table_mod(const double *t)
     return hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof(double) * kTimeSlots);
 }
 
-template <int MODE>
+template <int MODE, bool HAS_FX>
 static hipError_t launch(bool env, bool filt, hipStream_t st, const BankView &view, int first,
                          int count, int block_base, uint32_t clock_base, int n_blocks,
                          int span_total, float *partial, void *out)
@@ -18,7 +18,7 @@ static hipError_t launch(bool env, bool filt, hipStream_t st, const BankView &vi
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t smem = tile_bytes<MODE>();
-    auto kernel = voice_mod_kernel<MODE>;
+    auto kernel = voice_mod_kernel<MODE, HAS_FX>;
     if (dev < 16 && !configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -36,10 +36,13 @@ hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, cons
                              int first, int count, int block_base, uint32_t clock_base,
                              int n_blocks, int span_total, float *partial, void *out)
 {
-#define KLMI_MODE(M)                                                                        \
-    case M:                                                                                 \
-        return launch<M>(env, filt, st, view, first, count, block_base, clock_base, n_blocks, \
-                         span_total, partial, out)
+#define KLMI_MODE(M)                                                                         \
+    case M:                                                                                  \
+        return view.n_fx > 0                                                                 \
+                   ? launch<M, true>(env, filt, st, view, first, count, block_base, clock_base,  \
+                                     n_blocks, span_total, partial, out)                     \
+                   : launch<M, false>(env, filt, st, view, first, count, block_base, clock_base, \
+                                      n_blocks, span_total, partial, out)
     switch (mode) {
         KLMI_MODE(OUT_MIX_MONO);
         KLMI_MODE(OUT_MIX_STEREO);
