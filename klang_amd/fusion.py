@@ -18,6 +18,10 @@ with, optionally, one modulation source per voice:
 
 is replaced, together with the chain blocks, by one ``GpuVoiceBank`` block that
 owns a device-resident ``klang_amd.native.Bank`` (one voice per mixer input).
+A chain of effect stages / a Reverb whose source is NOT a device oscillator -- the
+output of a mixer, a synthesizer or any host block, as in the reference's
+examples/reverberation_demo.py:33-34 (``mixer | Reverb | Dac``) -- is fused too: its
+samples arrive per buffer as the bank's external input (KLMI_WAVE_EXTERNAL).
 ``PolyphonicSynthesizer`` / ``MonophonicSynthesizer`` blocks, alone
 or as the inputs of one mixer, become *gated* banks: one voice per synthesizer voice,
 updated only while active; the polyphonic note routing runs on the device.
@@ -75,6 +79,8 @@ class Chain:
         self.cutoff_lfo = None          # Lfo(shape=1) | filter.frequency
         self.mod_target = native.MOD_NONE
         self.modulator = None           # Lfo(shape=256) or FmOscillator.modulator
+        self.external = None            # the Output whose samples feed the first stage, when the
+                                        # source is not a device oscillator
         self._walk(end)
 
     def _check_stage(self, stage):
@@ -115,15 +121,23 @@ class Chain:
         return lfo
 
     def _walk(self, block):
-        stage = block
+        stage, first = block, None      # first: the earliest block of the chain seen so far
         if isinstance(stage, Reverb):
             if stage.echoType is not BackwardCombFilter:
                 raise NotFusable('%s: only BackwardCombFilter echoes run on the device' % stage)
-            self.reverb, stage = stage, self._upstream(stage)
+            self.reverb, first, stage = stage, stage, self._upstream(stage)
         while type(stage) in EFFECT_KINDS:
             self._check_stage(stage)
             self.stages.insert(0, stage)
-            stage = self._upstream(stage)
+            first, stage = stage, self._upstream(stage)
+        if first is not None and not isinstance(stage, (Voice, Oscillator, PwmOscillator)):
+            # the chain starts at someone else's output: external input, per buffer
+            if len(self.stages) > native.MAX_FX:
+                raise NotFusable('%s: more than %d effect stages in one chain'
+                                 % (block, native.MAX_FX))
+            self.external = first.input.incomingConnection
+            self.blocks = [b for b in [self.reverb, self.cutoff_lfo] + self.stages if b]
+            return
         if len(self.stages) > native.MAX_FX:
             raise NotFusable('%s: more than %d effect stages in one chain' % (block, native.MAX_FX))
         if isinstance(stage, Voice):
@@ -171,7 +185,8 @@ class Chain:
         src = block.input.incomingConnection
         if src is None or src.owner is None:
             raise NotFusable('%s has no upstream block' % block)
-        if len(src.outgoingConnections) != 1:
+        inside = isinstance(src.owner, (Voice, Phasor)) or type(src.owner) in EFFECT_KINDS
+        if inside and len(src.outgoingConnections) != 1:
             raise NotFusable('%s feeds more than one input' % src.owner)
         return src.owner
 
@@ -180,7 +195,8 @@ class Chain:
         rv = self.reverb
         return (self.voice is not None, self.filter is not None,
                 (rv.decay, rv.preDelay, rv.dryWet, rv.nEchos) if rv else None,
-                self.cutoff_lfo is not None, self.mod_target, self.program)
+                self.cutoff_lfo is not None, self.mod_target, self.program,
+                self.external is not None)
 
     @property
     def program(self):
@@ -189,6 +205,8 @@ class Chain:
         return () if kinds in ((), (native.FX_FILTER,)) else kinds
 
     def wave_id(self):
+        if self.external is not None:
+            return native.WAVE_EXTERNAL
         if isinstance(self.oscillator, PwmOscillator):
             return native.WAVE_PWM
         return WAVE_IDS[self.oscillator.wave_func]
@@ -206,7 +224,8 @@ class GpuVoiceBank(Block):
         self.poly = (self.synths[0].MAX_VOICES
                      if self.synths and isinstance(self.synths[0], PolyphonicSynthesizer) else 0)
         self.ctx = ctx or native.default_context()
-        has_env, has_filter, reverb, cutoff_lfo, mod_target, program = chains[0].shape
+        has_env, has_filter, reverb, cutoff_lfo, mod_target, program, external = chains[0].shape
+        self.external = external
         self.cutoff_lfo, self.mod_target, self.program = cutoff_lfo, mod_target, program
         self.stereo = isinstance(sink, StereoMixer)
         self.is_mixer = isinstance(sink, Mixer)
@@ -234,12 +253,13 @@ class GpuVoiceBank(Block):
         F, bank, ch = native, self.bank, self.chains
         oscs = [c.oscillator for c in ch]
         bank.set(F.F_WAVE, [c.wave_id() for c in ch])
-        if self.mod_target != F.MOD_FREQUENCY:
-            bank.set(F.F_FREQUENCY, [float(compute_rate(o.frequency.value)) for o in oscs])
-        bank.set(F.F_DUTY, [float(o.dutyCycle.value)
-                            if isinstance(o, PwmOscillator) and self.mod_target != F.MOD_DUTY else .5
-                            for o in oscs])
-        bank.set_state(F.F_PHASE, [float(o.currentPhase) for o in oscs])
+        if not self.external:
+            if self.mod_target != F.MOD_FREQUENCY:
+                bank.set(F.F_FREQUENCY, [float(compute_rate(o.frequency.value)) for o in oscs])
+            bank.set(F.F_DUTY, [float(o.dutyCycle.value)
+                                if isinstance(o, PwmOscillator) and self.mod_target != F.MOD_DUTY
+                                else .5 for o in oscs])
+            bank.set_state(F.F_PHASE, [float(o.currentPhase) for o in oscs])
         if self.mod_target != F.MOD_NONE:
             mods = [c.modulator for c in ch]
             fm = self.mod_target == F.MOD_FM
@@ -388,8 +408,10 @@ class GpuVoiceBank(Block):
                              'use lookahead=1 for patches with live message sources')
         if not self._ready:
             self._collect_events()
+            if self.external:
+                self._feed_external()
             # float32 [n][channels][256] -> per buffer (256,) mono or (2, 256) stereo
-            ahead = max(1, int(self.lookahead))
+            ahead = 1 if self.external else max(1, int(self.lookahead))
             if self.remaining is not None:
                 ahead = max(1, min(ahead, int(self.remaining)))
             mix = self.bank.render(ahead)
@@ -397,6 +419,17 @@ class GpuVoiceBank(Block):
         if self.remaining is not None:
             self.remaining -= 1
         self.sink.output.set_value(self._ready.pop().astype(np.float64))
+
+    def _feed_external(self):
+        """This buffer's samples of the chains' sources -> klmi_bank_set_input."""
+        rows = []
+        for c in self.chains:
+            value = np.asarray(c.external.value, dtype=np.float64)
+            if value.shape != (BUFFER_SIZE,):
+                raise KlangError('%s: the device chain takes mono buffers of %d samples, got shape '
+                                 '%s from %s' % (self, BUFFER_SIZE, value.shape, c.external.owner))
+            rows.append(value)
+        self.bank.set_input(np.stack(rows))
 
     def bounce(self, duration, fadeout=0., want_pcm=True):
         """The whole piece in one device pass (klmi_bank_bounce): notes queued so far are
@@ -415,9 +448,10 @@ class GpuVoiceBank(Block):
         """Copy device state back into the host blocks (currentPhase, envelope
         stage/value) so that the patch can be inspected or re-run on the host."""
         F, bank = native, self.bank
-        phase = bank.get_state(F.F_PHASE)
-        for i, c in enumerate(self.chains):
-            c.oscillator.currentPhase = float(phase[i])
+        if not self.external:
+            phase = bank.get_state(F.F_PHASE)
+            for i, c in enumerate(self.chains):
+                c.oscillator.currentPhase = float(phase[i])
         if self.mod_target != F.MOD_NONE:
             for c, p in zip(self.chains, bank.get_state(F.F_MOD_PHASE)):
                 c.modulator.currentPhase = float(p)
@@ -534,8 +568,9 @@ def find_fusable(exec_order):
         if type(blk) in (Phasor, Lfo):
             continue   # control-rate sources stay on the host
         consumers = [d.owner for o in blk.outputs for d in o.outgoingConnections]
-        if any(isinstance(c, (Reverb,) + tuple(EFFECT_KINDS)) and c not in claimed for c in consumers):
-            continue   # not the end of its chain
+        if not isinstance(blk, Reverb) and any(
+                isinstance(c, (Reverb,) + tuple(EFFECT_KINDS)) and c not in claimed for c in consumers):
+            continue   # not the end of its chain (a Reverb always is: what follows it starts anew)
         try:
             chain = Chain(blk)
             groups.append((blk, [chain], ()))

@@ -51,6 +51,8 @@ def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', of
     if len(banks) != 1 or any(b is not banks[0] and b is not dac for b in execOrder):
         return None
     bank = banks[0]
+    if bank.external:
+        return None
     feeds = [i.incomingConnection for i in dac.inputs if i.incomingConnection is not None]
     if (feeds != [bank.sink.output] or dac.inputs[0].incomingConnection is None
             or bank.bank.channels != dac.nChannels):

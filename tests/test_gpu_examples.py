@@ -1,0 +1,33 @@
+"""The example patches (examples/, rewritten from the reference's examples/) run through
+run_klang on the device and must equal the explicit host evaluation of the same blocks."""
+import importlib
+import wave
+
+import numpy as np
+import pytest
+
+from klang_amd.klang import run_klang
+
+pytestmark = pytest.mark.gpu
+B = 256
+
+
+@pytest.mark.parametrize('name,duration,channels', [
+    ('hello_world', .3, 1), ('haunting_envelopes', .5, 2), ('reverberation_demo', 1.6, 1),
+    ('synthesizer_demo', 1.5, 1)])
+def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, channels):
+    mod = importlib.import_module('examples.' + name)
+    out = {}
+    for backend in ('hip', 'host'):
+        path = str(tmp_path / ('%s_%s.wav' % (name, backend)))
+        frames = run_klang(mod.build(), backend=backend, filepath=path, offline=True,
+                           duration=duration, fadeout=.1)
+        with wave.open(path, 'rb') as wf:
+            assert wf.getnchannels() == channels and wf.getframerate() == 44100
+            pcm = np.frombuffer(wf.readframes(-1), dtype='<i2').astype(int)
+        out[backend] = (np.concatenate(frames), pcm)
+    got, want = out['hip'][0], out['host'][0]
+    assert got.shape == want.shape == (int(duration * 44100 // B) * B, channels)
+    assert np.abs(want).max() > .02
+    assert np.abs(got - want).max() <= 1e-5
+    assert np.abs(out['hip'][1] - out['host'][1]).max() <= 2   # int16 steps after normalisation

@@ -293,13 +293,17 @@ def test_fuser_recognises_effect_stages():
     plain = Oscillator() | Filter()
     groups, _ = fusion.find_fusable(determine_execution_order([plain]))
     assert groups[0][1][0].program == ()
-    # effects before a Reverb are fine, after it they are not
+    # effects before a Reverb belong to its chain; after it they form a chain of their own
+    # that takes the Reverb's output as external input
     ok = Oscillator() | TanhDistortion(2.) | Reverb()
     groups, errors = fusion.find_fusable(determine_execution_order([ok]))
     assert not errors and groups[0][1][0].program == (native.FX_TANH,)
-    bad = Oscillator() | Reverb() | Gain(.5)
-    groups, errors = fusion.find_fusable(determine_execution_order([bad]))
-    assert errors
+    rv = Reverb()
+    after = Oscillator() | rv | Gain(.5)
+    groups, errors = fusion.find_fusable(determine_execution_order([after]))
+    assert not errors and len(groups) == 2
+    tail = [c for _, (c,), _ in groups if c.external is not None]
+    assert len(tail) == 1 and tail[0].external is rv.output and tail[0].program == (native.FX_GAIN,)
     # refused: two delays, modulated gain, short delay
     two = Oscillator() | Delay(.01) | Delay(.02)
     _, errors = fusion.find_fusable(determine_execution_order([two]))

@@ -213,7 +213,7 @@ def test_find_fusable_matches_voice_filter_mixer():
     assert not errors and len(groups) == 1
     sink, chains, _ = groups[0]
     assert sink is mixer and len(chains) == 6
-    assert chains[0].shape == (True, True, None, False, 0, ())
+    assert chains[0].shape == (True, True, None, False, 0, (), False)
     assert [c.voice for c in chains] == voices and chains[0].wave_id() == 2
 
 
@@ -227,7 +227,7 @@ def test_find_fusable_single_chain_and_reverb_shape():
     dac = voice | rv | Dac()
     groups, errors = fusion.find_fusable(determine_execution_order([dac]))
     assert not errors and groups[0][0] is rv
-    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10), False, 0, ())
+    assert groups[0][1][0].shape == (True, False, (3., .03, .7, 10), False, 0, (), False)
 
 
 def test_find_fusable_reports_what_it_cannot_fuse():
@@ -402,7 +402,9 @@ def test_find_fusable_synthesizers():
     mixer += MonophonicSynthesizer(make())
     groups, errors = fusion.find_fusable(determine_execution_order([mixer | Dac()]))
     assert any('different kinds' in e for e in errors)
-    # effects after a synthesizer work on the summed signal: not a per-voice chain
-    syn = PolyphonicSynthesizer(make())
-    groups, errors = fusion.find_fusable(determine_execution_order([syn | Filter() | Dac()]))
-    assert any('not an oscillator' in e for e in errors)
+    # effects after a synthesizer work on the summed signal: a second bank that takes the
+    # synthesizer's output as external input (examples/reverberation_demo.py:33-34 shape)
+    syn, fil = PolyphonicSynthesizer(make()), Filter()
+    groups, errors = fusion.find_fusable(determine_execution_order([syn | fil | Dac()]))
+    assert not errors and [g[0] for g in groups] == [syn, fil]
+    assert groups[1][1][0].external is syn.output and groups[1][1][0].filter is fil
