@@ -16,12 +16,13 @@ from klang_amd.block import input_neighbors, output_neighbors
 
 def traverse_network(blocks):
     """All blocks reachable from `blocks` (in discovery order) and the edges."""
-    seen, edges = [], set()
+    seen, known, edges = [], set(), set()   # `known`: O(1) membership for large patches
     todo = collections.deque(blocks)
     while todo:
         blk = todo.popleft()
-        if blk in seen:
+        if blk in known:
             continue
+        known.add(blk)
         seen.append(blk)
         for nxt in output_neighbors(blk):
             edges.add((blk, nxt))

@@ -892,6 +892,37 @@ float ko_bounce(const float *bus, int n_blocks, int channels, double duration, d
     return peak;
 }
 
+/* ------------------------------------------------------------------------ */
+/* synthesizer.py:22-55, 253-283 Kick with waves.py:56-61 sample_wave: exponential amplitude
+ * and pitch decay over a sine.  sample_wave returns wrap(phase[-1] + TAU * frequency * DT)
+ * with the frequency ARRAY, so after the first buffer the kick's currentPhase is a vector of
+ * 256 start phases, one per sample position; a trigger (note-on with pitch > 0) resets it
+ * to the scalar 0 and currentTime to 0. */
+void ko_kick_block(ko_kick *k, int trigger, double *out)
+{
+    const double dt = 1. / KO_SAMPLING_RATE;
+    if (trigger) {
+        k->current_time = 0.;
+        for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+            k->current_phase[i] = 0.;
+    }
+    const double cd = -KO_PI / k->decay, cp = -KO_PI / k->pitch_decay;
+    const double amp_d = exp(cd * k->current_time), amp_p = exp(cp * k->current_time);
+    double w[KO_BUFFER_SIZE], last = 0.;
+    for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+        const double t = dt * (double)i;
+        const double env = amp_d * exp(cd * t);
+        const double pitch = k->frequency * (1. + k->intensity * (amp_p * exp(cp * t)));
+        w[i] = KO_TAU * pitch;
+        const double phase = w[i] * t + k->current_phase[i];
+        out[i] = env * sin(phase);
+        last = phase;
+    }
+    for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+        k->current_phase[i] = ko_wrap(last + w[i] * dt);
+    k->current_time = k->current_time + dt * KO_BUFFER_SIZE;
+}
+
 int ko_max_threads(void)
 {
 #ifdef _OPENMP

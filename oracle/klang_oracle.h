@@ -210,6 +210,14 @@ void ko_synth_render(ko_bank *bank, int poly, int mono, int32_t *round_robin,
 float ko_bounce(const float *bus, int n_blocks, int channels, double duration, double fadeout,
                 float *frames, int16_t *pcm);
 
+/* ---- synthesizer.py Kick ---------------------------------------------------- */
+typedef struct {
+    double frequency, decay, intensity, pitch_decay; /* synthesizer.py:257: 40, .8, 2, .3 */
+    double current_time;
+    double current_phase[KO_BUFFER_SIZE];
+} ko_kick;
+void ko_kick_block(ko_kick *kick, int trigger, double *out /* 256 */);
+
 int ko_max_threads(void);
 
 #ifdef __cplusplus

@@ -58,6 +58,12 @@ NOTE_DTYPE = np.dtype([('instrument', '<u4'), ('block', '<u4'), ('pitch', '<i4')
                        ('reserved', '<u4'), ('velocity', '<f8'), ('frequency', '<f8')])
 
 
+class Kick(C.Structure):
+    _fields_ = [('frequency', C.c_double), ('decay', C.c_double), ('intensity', C.c_double),
+                ('pitch_decay', C.c_double), ('current_time', C.c_double),
+                ('current_phase', C.c_double * BUFFER_SIZE)]
+
+
 class Bank(C.Structure):
     _fields_ = [
         ('n_voices', C.c_int), ('has_env', C.c_int), ('has_filter', C.c_int), ('stereo', C.c_int),
@@ -141,6 +147,7 @@ def lib():
         L.ko_bounce.restype = C.c_float
         L.ko_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                                 C.c_void_p, C.c_void_p]
+        L.ko_kick_block.argtypes = [C.POINTER(Kick), C.c_int, _dp]
         L.ko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -498,6 +505,26 @@ def bounce(bus, duration, fadeout=0., want_pcm=True):
     peak = lib().ko_bounce(bus.ctypes.data, n_blocks, channels, float(duration), float(fadeout),
                            frames.ctypes.data, pcm.ctypes.data if want_pcm else None)
     return frames, pcm, float(peak)
+
+
+class OracleKick:
+    """klang.audio.synthesizer.Kick (synthesizer.py:253-283)."""
+
+    def __init__(self, frequency=40., decay=.8, intensity=2., pitch_decay=.3):
+        self.c = Kick(frequency, decay, intensity, pitch_decay, 0.)
+
+    def block(self, trigger=False):
+        out = np.empty(BUFFER_SIZE)
+        lib().ko_kick_block(C.byref(self.c), int(bool(trigger)), _p(out))
+        return out
+
+    @property
+    def current_phase(self):
+        return np.array(self.c.current_phase[:])
+
+    @property
+    def current_time(self):
+        return self.c.current_time
 
 
 def max_threads():

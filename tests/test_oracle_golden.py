@@ -620,3 +620,19 @@ def test_bounce_pcm_bit_exact(oracle, golden, name, ch):
 def test_bounce_of_silence_has_zero_peak(oracle):
     frames, pcm, peak = oracle.bounce(np.zeros((3, 1, B), dtype=np.float32), .02, 0.)
     assert peak == 0. and not pcm.any()
+
+
+@pytest.mark.parametrize('name,kw,triggers', [
+    ('kick_default', {}, (0, 70)),
+    ('kick_tom', dict(frequency=110., decay=.25, intensity=3.5, pitch_decay=.08), (3,))])
+def test_kick_drum(oracle, golden, name, kw, triggers):
+    """Kick (synthesizer.py:253-283) incl. its vector currentPhase; np.exp / np.sin vs glibc:
+    ulp-level differences, fed back through the phase."""
+    g = golden('synthesizer')
+    want = g[name + '_out']
+    kick = oracle.OracleKick(**kw)
+    got = np.array([kick.block(b in triggers) for b in range(len(want))])
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert np.abs(want).max() > .5
+    assert abs(kick.current_time - g[name + '_final'][0]) <= 1e-12
+    np.testing.assert_allclose(kick.current_phase, g[name + '_final'][1:], rtol=0, atol=1e-9)

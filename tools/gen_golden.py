@@ -572,6 +572,23 @@ def main():
         syn['mono_%s_state' % policy] = np.array([mono.voice.oscillator.currentPhase,
                                                   mono.voice.currentPitch, mono.voice.amplitude])
     syn['mono_notes'] = notes_array(script1)
+    # Kick (synthesizer.py:253-283): default drum, triggered at buffers 0 and 70, and a
+    # higher, shorter one triggered once; note-offs and pitch 0 do not trigger
+    import warnings
+    for name, kw, hits in (('kick_default', {}, {0: E(36), 30: E(36, 0.), 70: E(36)}),
+                           ('kick_tom', dict(frequency=110., decay=.25, intensity=3.5, pitchDecay=.08),
+                            {3: E(50), 9: E(0)})):
+        kick = SY.Kick(**kw)
+        outs = []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for b in range(100):
+                if b in hits:
+                    kick.input.push(hits[b])
+                kick.update()
+                outs.append(np.array(kick.output.value, dtype=float))
+        syn[name + '_out'] = np.array(outs)
+        syn[name + '_final'] = np.r_[kick.currentTime, np.broadcast_to(kick.currentPhase, (B,))]
     syn['template'] = np.array([.004, .02, .6, .012])
     save('synthesizer', **syn)
 
