@@ -229,6 +229,7 @@ typedef struct klmi_ctx klmi_ctx;
 typedef struct klmi_bank klmi_bank;
 typedef struct klmi_env klmi_env;
 typedef struct klmi_comb klmi_comb;
+typedef struct klmi_kick klmi_kick;
 
 const char *klmi_last_error(void);
 const char *klmi_version(void);
@@ -364,6 +365,28 @@ int klmi_comb_create(klmi_ctx *ctx, int kind, int count, int length, double alph
 int klmi_comb_destroy(klmi_comb *comb);
 int klmi_comb_set_alpha(klmi_comb *comb, int first, int count, const double *host);
 int klmi_comb_filter(klmi_comb *comb, const double *host_x, long n, double *host_y);
+
+/* ---- kick drums: klang.audio.synthesizer.Kick, x count ---------------------- */
+/* synthesizer.py:253-283 (with sample_exponential_decay / sample_pitch_decay :22-55 and
+ * waves.py:56-61 sample_wave): ctor defaults frequency 40, decay .8, intensity 2,
+ * pitchDecay .3.  klmi_kick_trigger queues the buffers (relative to the next render) at
+ * which a note-on with pitch > 0 reaches a kick (currentTime and currentPhase back to 0);
+ * klmi_kick_render = update() x n_blocks -> float64[count][n_blocks*256].  State fields:
+ * currentTime [count], currentPhase [count][256] (a vector after the first buffer, as in
+ * the reference). */
+typedef enum {
+    KLMI_KICK_FREQUENCY = 0,
+    KLMI_KICK_DECAY = 1,
+    KLMI_KICK_INTENSITY = 2,
+    KLMI_KICK_PITCH_DECAY = 3
+} klmi_kick_field;
+int klmi_kick_create(klmi_ctx *ctx, int count, klmi_kick **out);
+int klmi_kick_destroy(klmi_kick *kick);
+int klmi_kick_set(klmi_kick *kick, int field, int first, int count, const double *host);
+int klmi_kick_trigger(klmi_kick *kick, const uint32_t *which, const uint32_t *block, size_t n);
+int klmi_kick_render(klmi_kick *kick, int n_blocks, double *host_out);
+int klmi_kick_state_get(klmi_kick *kick, double *host_time /* [count] */,
+                        double *host_phase /* [count][256] */);
 
 #ifdef __cplusplus
 }

@@ -5,19 +5,26 @@ gated device bank (klang_amd/fusion.py): the polyphonic routing then runs on the
 device (klmi_bank_notes), the monophonic NoteScheduler stays here because it is
 a sequential heap per instrument.
 
-Not mirrored: ``HiHat`` (white noise from NumPy's global RNG: no parity is
-possible) and ``Kick`` (its ``currentPhase`` turns into a 256-vector after the
-first buffer, synthesizer.py:282 with waves.py:61).
+``Kick`` is mirrored with the reference's behaviour as it is: its
+``currentPhase`` turns into a 256-vector after the first buffer
+(synthesizer.py:282 with waves.py:61).  Not mirrored: ``HiHat`` (white noise
+from NumPy's global RNG: no parity is possible).
 """
 import copy
 import heapq
 import itertools
+import math
 
-from klang_amd.audio.signals import MONO_SILENCE
+import numpy as np
+
+from klang_amd.audio.signals import DT, MONO_SILENCE, T
+from klang_amd.config import BUFFER_SIZE
+from klang_amd.constants import PI, TAU
 from klang_amd.block import Block
 from klang_amd.wiring import MessageInput
 
-__all__ = ['NoteScheduler', 'Synthesizer', 'MonophonicSynthesizer', 'PolyphonicSynthesizer']
+__all__ = ['NoteScheduler', 'Synthesizer', 'MonophonicSynthesizer', 'PolyphonicSynthesizer',
+           'Kick']
 
 
 def duplicate_voice(voice, number):
@@ -141,3 +148,43 @@ class PolyphonicSynthesizer(Synthesizer):
                 voice.update()
                 samples += voice.output.value
         self.output.set_value(samples / self.MAX_VOICES)
+
+
+def sample_exponential_decay(decay, t0=0.):
+    """exp(-PI / decay * (t0 + T)) as amplitude-at-t0 times the curve over one buffer, and
+    the next start time (synthesizer.py:22-36)."""
+    amp = math.exp(-PI / decay * t0)
+    return amp * np.exp(-PI / decay * T), t0 + DT * BUFFER_SIZE
+
+
+def sample_pitch_decay(frequency, decay, intensity, t0=0.):
+    """synthesizer.py:39-55."""
+    env, t1 = sample_exponential_decay(decay, t0)
+    return frequency * (1. + intensity * env), t1
+
+
+class Kick(Block):
+    """Kick drum: a sine with exponentially decaying amplitude and pitch, re-started by every
+    note-on with pitch > 0 (synthesizer.py:253-283).  As in the reference the next start
+    phase is wrap(phase[-1] + TAU * frequency * DT) with the frequency ARRAY (waves.py:61):
+    a vector of 256 start phases from the second buffer on."""
+
+    def __init__(self, frequency=40., decay=.8, intensity=2, pitchDecay=.3):
+        super().__init__(nInputs=0, nOutputs=1)
+        self.frequency, self.decay = frequency, decay
+        self.intensity, self.pitchDecay = intensity, pitchDecay
+        self.inputs = [MessageInput(self)]
+        self.currentTime = 0.
+        self.currentPhase = 0.
+
+    def update(self):
+        for note in self.input.receive():
+            if note.pitch > 0 and note.on:
+                self.currentTime = 0.
+                self.currentPhase = 0.
+        frequency, _ = sample_pitch_decay(self.frequency, self.pitchDecay, self.intensity,
+                                          self.currentTime)
+        env, self.currentTime = sample_exponential_decay(self.decay, self.currentTime)
+        phase = TAU * frequency * T + self.currentPhase                      # waves.py:60
+        self.currentPhase = (phase[-1] + TAU * frequency * DT + PI) % TAU - PI  # waves.py:61
+        self.output.set_value(env * np.sin(phase))

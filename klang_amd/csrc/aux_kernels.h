@@ -93,4 +93,52 @@ __global__ void ring_filter_kernel(int count, int length, int position, long n,
     }
 }
 
+// klang.audio.synthesizer.Kick x count (synthesizer.py:22-55, 253-283, waves.py:56-61): one
+// workgroup of 256 threads = one kick, thread = sample position i of the buffer.  The kick's
+// currentPhase is a VECTOR of 256 start phases after its first buffer (sample_wave returns
+// wrap(phase[-1] + TAU * frequency * DT) with the frequency array), so every thread carries
+// its own phase and needs the last thread's phase of the buffer: one LDS broadcast per buffer.
+// par: [4][count] frequency, decay, intensity, pitchDecay; state: time [count], phase
+// [count][256]; trig: [count][n_blocks] 1 where a note-on with pitch > 0 arrives;
+// out: [count][n_blocks*256] float64.
+__global__ __launch_bounds__(kBlock) void kick_kernel(int count, int n_blocks,
+                                                      const double *__restrict__ par,
+                                                      double *__restrict__ time_state,
+                                                      double *__restrict__ phase_state,
+                                                      const unsigned char *__restrict__ trig,
+                                                      const double *__restrict__ t_table,
+                                                      double *__restrict__ out)
+{
+    __shared__ double last_phase;
+    const int k = blockIdx.x, i = threadIdx.x;
+    const double frequency = par[k], decay = par[count + k];
+    const double intensity = par[2 * (size_t)count + k], pitch_decay = par[3 * (size_t)count + k];
+    const double cd = -kPi / decay, cp = -kPi / pitch_decay;   // -PI / decay * t
+    const double t = t_table[i];                                // helpers.py:30 T
+    double time = time_state[k];
+    double phase0 = phase_state[(size_t)k * kBlock + i];
+    const double shape_d = exp(cd * t), shape_p = exp(cp * t);  // np.exp(-PI / decay * T)
+    for (int b = 0; b < n_blocks; ++b) {
+        if (trig[(size_t)k * n_blocks + b]) {                   // synthesizer.py:275-278
+            time = 0.;
+            phase0 = 0.;
+        }
+        const double env = exp(cd * time) * shape_d;            // synthesizer.py:34-35
+        const double pitch = frequency * (1. + intensity * (exp(cp * time) * shape_p));
+        const double w = kTau * pitch;
+        const double phase = w * t + phase0;                    // waves.py:60
+        out[((size_t)k * n_blocks + b) * kBlock + i] = env * sin(phase);
+        if (i == kBlock - 1)
+            last_phase = phase;
+        __syncthreads();
+        const double x = last_phase + w * kDt + kPi;            // waves.py:61, math.py:9-11 wrap
+        phase0 = np_mod_tau(x) - kPi;
+        time = time + kDt * kBlock;                             // synthesizer.py:36
+        __syncthreads();
+    }
+    phase_state[(size_t)k * kBlock + i] = phase0;
+    if (i == 0)
+        time_state[k] = time;
+}
+
 }  // namespace klmi

@@ -2151,3 +2151,137 @@ extern "C" int klmi_comb_filter(klmi_comb *c, const double *host_x, long n, doub
             host_y[(size_t)f * n + i] = t[(size_t)i * c->count + f];
     return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// kick drums (klang.audio.synthesizer.Kick x count)
+// ---------------------------------------------------------------------------------
+struct klmi_kick {
+    klmi_ctx *ctx = nullptr;
+    int count = 0;
+    DevBuf<double> par, time, phase, out, t_table;
+    DevBuf<unsigned char> trig;
+    std::vector<std::pair<uint32_t, uint32_t>> pending;  // (kick, block relative to next render)
+};
+
+extern "C" int klmi_kick_create(klmi_ctx *ctx, int count, klmi_kick **out)
+{
+    TRY(use(ctx));
+    if (!out || count <= 0)
+        return fail(KLMI_E_ARG, "klmi_kick_create: bad argument");
+    klmi_kick *k = new klmi_kick;
+    k->ctx = ctx;
+    k->count = count;
+    std::vector<double> par((size_t)4 * count), t(kBlock);
+    const double defaults[4] = {40., .8, 2., .3};  // synthesizer.py:257
+    for (int f = 0; f < 4; ++f)
+        std::fill_n(par.begin() + (size_t)f * count, count, defaults[f]);
+    for (int i = 0; i < kBlock; ++i)
+        t[i] = kDt * (double)i;
+    hipError_t e = k->par.alloc(par.size());
+    if (e == hipSuccess) e = k->time.alloc(count);
+    if (e == hipSuccess) e = k->phase.alloc((size_t)count * kBlock);
+    if (e == hipSuccess) e = k->t_table.alloc(kBlock);
+    if (e == hipSuccess) e = hipMemset(k->time.p, 0, sizeof(double) * count);
+    if (e == hipSuccess) e = hipMemset(k->phase.p, 0, sizeof(double) * count * kBlock);
+    if (e == hipSuccess)
+        e = hipMemcpy(k->par.p, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(k->t_table.p, t.data(), sizeof(double) * kBlock, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        delete k;
+        return fail(KLMI_E_MEMORY, "klmi_kick_create: %s", hipGetErrorString(e));
+    }
+    ctx->live_objects++;
+    *out = k;
+    return 0;
+}
+
+extern "C" int klmi_kick_destroy(klmi_kick *kick)
+{
+    if (!kick)
+        return 0;
+    (void)hipSetDevice(kick->ctx->device);
+    (void)hipStreamSynchronize(kick->ctx->stream);
+    kick->ctx->live_objects--;
+    delete kick;
+    return 0;
+}
+
+extern "C" int klmi_kick_set(klmi_kick *k, int field, int first, int count, const double *host)
+{
+    if (!k || !host)
+        return fail(KLMI_E_ARG, "klmi_kick_set: null argument");
+    if (field < KLMI_KICK_FREQUENCY || field > KLMI_KICK_PITCH_DECAY)
+        return fail(KLMI_E_ARG, "klmi_kick_set: unknown field %d", field);
+    if (first < 0 || count < 0 || (long)first + count > k->count)
+        return fail(KLMI_E_ARG, "klmi_kick_set: range [%d, %d) outside %d kicks", first,
+                    first + count, k->count);
+    if (field == KLMI_KICK_DECAY || field == KLMI_KICK_PITCH_DECAY)
+        for (int i = 0; i < count; ++i)
+            if (!(host[i] > 0.))  // the reference divides by it (synthesizer.py:34)
+                return fail(KLMI_E_ARG, "klmi_kick_set: decay times must be > 0, got %g", host[i]);
+    TRY(use(k->ctx));
+    HIP_TRY(hipStreamSynchronize(k->ctx->stream));
+    HIP_TRY(hipMemcpy(k->par.p + (size_t)field * k->count + first, host, sizeof(double) * count,
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int klmi_kick_trigger(klmi_kick *k, const uint32_t *which, const uint32_t *block,
+                                 size_t n)
+{
+    if (!k || (n && (!which || !block)))
+        return fail(KLMI_E_ARG, "klmi_kick_trigger: null argument");
+    for (size_t i = 0; i < n; ++i)
+        if (which[i] >= (uint32_t)k->count)
+            return fail(KLMI_E_ARG, "klmi_kick_trigger: trigger %zu addresses kick %u of %d", i,
+                        which[i], k->count);
+    for (size_t i = 0; i < n; ++i)
+        k->pending.emplace_back(which[i], block[i]);
+    return 0;
+}
+
+extern "C" int klmi_kick_render(klmi_kick *k, int n_blocks, double *host_out)
+{
+    if (!k || !host_out)
+        return fail(KLMI_E_ARG, "klmi_kick_render: null argument");
+    if (n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_kick_render: n_blocks must be positive, got %d", n_blocks);
+    TRY(use(k->ctx));
+    hipStream_t st = k->ctx->stream;
+    const size_t cells = (size_t)k->count * n_blocks;
+    std::vector<unsigned char> trig(cells, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> later;
+    for (const auto &p : k->pending) {
+        if (p.second < (uint32_t)n_blocks)
+            trig[(size_t)p.first * n_blocks + p.second] = 1;
+        else
+            later.emplace_back(p.first, p.second - (uint32_t)n_blocks);
+    }
+    k->pending.swap(later);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(k->trig.reserve(cells));
+    HIP_TRY(k->out.reserve(cells * kBlock));
+    HIP_TRY(hipMemcpyAsync(k->trig.p, trig.data(), cells, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kick_kernel, dim3(k->count), dim3(kBlock), 0, st, k->count, n_blocks,
+                       k->par.p, k->time.p, k->phase.p, k->trig.p, k->t_table.p, k->out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_out, k->out.p, sizeof(double) * cells * kBlock,
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // `trig` dies here
+    return 0;
+}
+
+extern "C" int klmi_kick_state_get(klmi_kick *k, double *host_time, double *host_phase)
+{
+    if (!k)
+        return fail(KLMI_E_ARG, "klmi_kick_state_get: null kick");
+    TRY(use(k->ctx));
+    HIP_TRY(hipStreamSynchronize(k->ctx->stream));
+    if (host_time)
+        HIP_TRY(hipMemcpy(host_time, k->time.p, sizeof(double) * k->count, hipMemcpyDeviceToHost));
+    if (host_phase)
+        HIP_TRY(hipMemcpy(host_phase, k->phase.p, sizeof(double) * k->count * kBlock,
+                          hipMemcpyDeviceToHost));
+    return 0;
+}

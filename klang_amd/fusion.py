@@ -45,7 +45,7 @@ from klang_amd.audio.filtering import BackwardCombFilter, Filter, Reverb
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.signals import (BUFFER_SIZE, SCALAR, FmOscillator, Lfo, Oscillator, Phasor,
                                       PwmOscillator, WAVE_IDS)
-from klang_amd.audio.synthesizer import (MonophonicSynthesizer, PolyphonicSynthesizer,
+from klang_amd.audio.synthesizer import (Kick, MonophonicSynthesizer, PolyphonicSynthesizer,
                                          Synthesizer)
 from klang_amd.audio.voices import Voice
 from klang_amd.block import Block
@@ -59,7 +59,7 @@ EFFECT_KINDS = {Filter: native.FX_FILTER, Gain: native.FX_GAIN, Transformer: nat
                 Subsampler: native.FX_SUBSAMPLE, Bitcrusher: native.FX_BITCRUSH,
                 RingModulator: native.FX_RINGMOD}
 ONE_PER_CHAIN = (Filter, Tremolo, Delay, Subsampler, RingModulator)   # stateful stages
-HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer, Synthesizer) + tuple(
+HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer, Synthesizer, Kick) + tuple(
     t for t in EFFECT_KINDS if t is not Filter)
 
 
@@ -71,7 +71,9 @@ class Chain:
     """One voice chain, source first: oscillator [+ envelope via Voice]
     [-> Filter] [-> Reverb]; `end` is the block whose output leaves the chain."""
 
-    def __init__(self, end):
+    def __init__(self, end=None, external=None):
+        """Chain(end): the chain that ends in block `end`.  Chain(external=output): no block
+        at all, just somebody's output as a voice (a mixer input that is not a device chain)."""
         self.end = end
         self.blocks = []
         self.voice = self.oscillator = self.envelope = self.filter = self.reverb = None
@@ -79,9 +81,10 @@ class Chain:
         self.cutoff_lfo = None          # Lfo(shape=1) | filter.frequency
         self.mod_target = native.MOD_NONE
         self.modulator = None           # Lfo(shape=256) or FmOscillator.modulator
-        self.external = None            # the Output whose samples feed the first stage, when the
+        self.external = external        # the Output whose samples feed the first stage, when the
                                         # source is not a device oscillator
-        self._walk(end)
+        if end is not None:
+            self._walk(end)
 
     def _check_stage(self, stage):
         kind = type(stage)
@@ -516,6 +519,40 @@ def synth_chains(synths):
     return chains
 
 
+class GpuKick(Block):
+    """One Kick block evaluated on the device (klmi_kick_*, count 1): the kick's own Output
+    carries the result.  One block per Kick keeps every kick at its place in the execution
+    order; callers that can batch use native.KickBatch directly."""
+
+    def __init__(self, kick, ctx=None):
+        super().__init__()
+        self.kick = kick
+        if kick.currentTime != 0. or np.any(kick.currentPhase):
+            raise NotFusable('%s has already played on the host' % kick)
+        self.batch = native.KickBatch(ctx or native.default_context(), 1)
+        for field, value in ((native.KICK_FREQUENCY, kick.frequency), (native.KICK_DECAY, kick.decay),
+                             (native.KICK_INTENSITY, kick.intensity),
+                             (native.KICK_PITCH_DECAY, kick.pitchDecay)):
+            self.batch.set(field, [float(value)])
+        self.lookahead, self.remaining = 1, None    # set by run_klang; a kick never renders ahead
+
+    def update(self):
+        for note in self.kick.input.receive():      # synthesizer.py:275-278
+            if note.pitch > 0 and note.on:
+                self.batch.trigger(0, 0)
+        self.kick.output.set_value(self.batch.render(1)[0])
+
+    def sync_host_blocks(self):
+        time, phase = self.batch.state()
+        self.kick.currentTime, self.kick.currentPhase = float(time[0]), phase[0].copy()
+
+    def close(self):
+        self.batch.close()
+
+    def __str__(self):
+        return 'GpuKick(%s)' % self.kick
+
+
 def _flat(order):
     for blk in order:
         yield blk
@@ -552,7 +589,15 @@ def find_fusable(exec_order):
                 claimed.update(b for c in chains for b in c.blocks)
                 claimed.add(blk)
             except NotFusable as err:
-                errors.append(str(err))
+                # Not uniform device chains.  The mixer still sums on the device: its inputs
+                # arrive per buffer as external voices, and whatever produces them is fused
+                # (or not) on its own further down.
+                outputs = [inp.incomingConnection for inp in blk.inputs]
+                if all(o is not None and o.owner is not None for o in outputs):
+                    groups.append((blk, [Chain(external=o) for o in outputs], ()))
+                    claimed.add(blk)
+                else:
+                    errors.append(str(err))
     # synthesizers that feed something other than a fused mixer: a bank each
     for blk in exec_order:
         if isinstance(blk, Synthesizer) and blk not in claimed:
@@ -592,6 +637,12 @@ def compile_order(exec_order, ctx=None, strict=True):
         fused_blocks.update(synths)
         fused_blocks.add(sink)
         banks_at[sink] = bank
+    for blk in exec_order:
+        if isinstance(blk, Kick):
+            try:
+                banks_at[blk] = GpuKick(blk, ctx)
+            except NotFusable as err:
+                errors.append(str(err))
     new_order = []
     for blk in exec_order:
         if blk in banks_at:

@@ -67,6 +67,8 @@ EXPORTS = [
     'klmi_bank_bounce_device', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
     'klmi_env_get', 'klmi_env_gate', 'klmi_env_sample', 'klmi_env_active', 'klmi_comb_create',
     'klmi_comb_destroy', 'klmi_comb_set_alpha', 'klmi_comb_filter',
+    'klmi_kick_create', 'klmi_kick_destroy', 'klmi_kick_set', 'klmi_kick_trigger',
+    'klmi_kick_render', 'klmi_kick_state_get',
 ]
 
 
@@ -147,6 +149,12 @@ def load():
     L.klmi_comb_destroy.argtypes = [_vp]
     L.klmi_comb_set_alpha.argtypes = [_vp, C.c_int, C.c_int, _dp]
     L.klmi_comb_filter.argtypes = [_vp, _dp, C.c_long, _dp]
+    L.klmi_kick_create.argtypes = [_vp, C.c_int, C.POINTER(_vp)]
+    L.klmi_kick_destroy.argtypes = [_vp]
+    L.klmi_kick_set.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
+    L.klmi_kick_trigger.argtypes = [_vp, _vp, _vp, C.c_size_t]
+    L.klmi_kick_render.argtypes = [_vp, C.c_int, _dp]
+    L.klmi_kick_state_get.argtypes = [_vp, _dp, _dp]
     _lib = L
     return L
 
@@ -532,3 +540,48 @@ class CombBatch:
         y = np.empty_like(x)
         _check(load().klmi_comb_filter(self._h, _p(x), x.shape[1], _p(y)))
         return y
+
+
+KICK_FREQUENCY, KICK_DECAY, KICK_INTENSITY, KICK_PITCH_DECAY = range(4)
+
+
+class KickBatch:
+    """count x klang.audio.synthesizer.Kick on the device (klmi_kick_*)."""
+
+    def __init__(self, ctx, count):
+        self.ctx, self.count = ctx, int(count)
+        self._h = _vp()
+        _check(load().klmi_kick_create(ctx._h, self.count, C.byref(self._h)))
+        _live_objects.add(self)
+        ctx._children.add(self)
+
+    def close(self):
+        if self._h:
+            load().klmi_kick_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set(self, field, values, first=0):
+        values = _f64(values).ravel()
+        _check(load().klmi_kick_set(self._h, field, first, values.size, _p(values)))
+
+    def trigger(self, which, block):
+        which = np.ascontiguousarray(np.atleast_1d(which), dtype=np.uint32)
+        block = np.ascontiguousarray(np.atleast_1d(block), dtype=np.uint32)
+        _check(load().klmi_kick_trigger(self._h, which.ctypes.data_as(_vp),
+                                        block.ctypes.data_as(_vp), which.size))
+
+    def render(self, n_blocks):
+        out = np.empty((self.count, int(n_blocks) * BUFFER_SIZE))
+        _check(load().klmi_kick_render(self._h, int(n_blocks), _p(out)))
+        return out
+
+    def state(self):
+        time, phase = np.empty(self.count), np.empty((self.count, BUFFER_SIZE))
+        _check(load().klmi_kick_state_get(self._h, _p(time), _p(phase)))
+        return time, phase

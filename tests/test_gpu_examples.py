@@ -14,7 +14,7 @@ B = 256
 
 @pytest.mark.parametrize('name,duration,channels', [
     ('hello_world', .3, 1), ('haunting_envelopes', .5, 2), ('reverberation_demo', 1.6, 1),
-    ('synthesizer_demo', 1.5, 1)])
+    ('synthesizer_demo', 1.5, 1), ('drum_machine', 2.2, 1)])
 def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, channels):
     mod = importlib.import_module('examples.' + name)
     out = {}

@@ -173,3 +173,47 @@ def test_argument_errors(hip, ctx):
     with pytest.raises(hip.NativeError):
         bank.set_state(hip.F_ROUND_ROBIN, [24.])
     bank.close()
+
+
+# ---- Kick (synthesizer.py:253-283) -----------------------------------------------------------
+def test_kick_batch_vs_reference(hip, ctx, golden):
+    """Two kicks in one batch, three render calls; float64 streams vs the real reference
+    (np.exp / np.sin vs the device's: ulp-level differences fed back through the phase)."""
+    g = golden('synthesizer')
+    batch = hip.KickBatch(ctx, 2)
+    for field, value in ((hip.KICK_FREQUENCY, 110.), (hip.KICK_DECAY, .25),
+                         (hip.KICK_INTENSITY, 3.5), (hip.KICK_PITCH_DECAY, .08)):
+        batch.set(field, [value], first=1)
+    batch.trigger([0, 0, 1], [0, 70, 3])
+    out = np.concatenate([batch.render(k) for k in (1, 30, 69)], axis=1)
+    for i, name in enumerate(('kick_default', 'kick_tom')):
+        want = g[name + '_out'].ravel()
+        assert np.abs(out[i] - want).max() <= 1e-11, name
+    time, phase = batch.state()
+    for i, name in enumerate(('kick_default', 'kick_tom')):
+        assert abs(time[i] - g[name + '_final'][0]) <= 1e-12
+        assert np.abs(phase[i] - g[name + '_final'][1:]).max() <= 1e-9
+    with pytest.raises(hip.NativeError):
+        batch.trigger([2], [0])
+    with pytest.raises(hip.NativeError):
+        batch.set(hip.KICK_DECAY, [0.])
+    batch.close()
+
+
+def test_many_kicks_vs_oracle(hip, ctx, oracle):
+    rng = np.random.default_rng(3)
+    n, nb = 300, 20
+    batch = hip.KickBatch(ctx, n)
+    par = np.stack([30. + 200. * rng.random(n), .05 + rng.random(n), 4. * rng.random(n),
+                    .02 + .5 * rng.random(n)])
+    for field in range(4):
+        batch.set(field, par[field])
+    hits = rng.random((n, nb)) < .15
+    which, block = np.nonzero(hits)
+    batch.trigger(which, block)
+    got = batch.render(nb)
+    for i in range(0, n, 7):
+        kick = oracle.OracleKick(*par[:, i])
+        want = np.concatenate([kick.block(hits[i, b]) for b in range(nb)])
+        assert np.abs(got[i] - want).max() <= 1e-11
+    batch.close()

@@ -240,9 +240,10 @@ def test_find_fusable_reports_what_it_cannot_fuse():
     shared = Oscillator()
     m = Mixer()
     m += shared
-    shared.output.connect(Block(1, 0).input)      # second consumer
-    _, errors = fusion.find_fusable(determine_execution_order([m]))
-    assert any('more than one input' in e for e in errors)
+    shared.output.connect(Block(1, 0).input)      # second consumer: the oscillator's stream is
+    groups, errors = fusion.find_fusable(determine_execution_order([m]))   # needed outside
+    assert not errors and [g[0] for g in groups] == [m, shared]
+    assert groups[0][1][0].external is shared.output                # the mixer takes it as input
 
 
 # ---- effects: host blocks vs the reference's fixtures ------------------------------
@@ -401,7 +402,9 @@ def test_find_fusable_synthesizers():
     mixer += PolyphonicSynthesizer(make())
     mixer += MonophonicSynthesizer(make())
     groups, errors = fusion.find_fusable(determine_execution_order([mixer | Dac()]))
-    assert any('different kinds' in e for e in errors)
+    # different kinds: a bank each, and the mixer sums their outputs as external voices
+    assert not errors and len(groups) == 3 and groups[0][0] is mixer
+    assert all(c.external is not None for c in groups[0][1])
     # effects after a synthesizer work on the summed signal: a second bank that takes the
     # synthesizer's output as external input (examples/reverberation_demo.py:33-34 shape)
     syn, fil = PolyphonicSynthesizer(make()), Filter()
