@@ -230,6 +230,7 @@ typedef struct klmi_bank klmi_bank;
 typedef struct klmi_env klmi_env;
 typedef struct klmi_comb klmi_comb;
 typedef struct klmi_kick klmi_kick;
+typedef struct klmi_chirp klmi_chirp;
 
 const char *klmi_last_error(void);
 const char *klmi_version(void);
@@ -387,6 +388,27 @@ int klmi_kick_trigger(klmi_kick *kick, const uint32_t *which, const uint32_t *bl
 int klmi_kick_render(klmi_kick *kick, int n_blocks, double *host_out);
 int klmi_kick_state_get(klmi_kick *kick, double *host_time /* [count] */,
                         double *host_phase /* [count][256] */);
+
+/* ---- chirp oscillators: klang.audio.oscillators.Chirper, x count ------------- */
+/* oscillators.py:280-308: wave_func(chirp_phase(t, startFrequency, duration, endFrequency,
+ * method)) with scipy.signal's _chirp_phase (vertex_zero=True) and the chirper's own time
+ * vector t (starts as DT * arange(256), gains DT * 256 per element and buffer; _reset puts
+ * it back).  wave: klmi_wave sine..triangle.  Invalid combinations fail with scipy's
+ * messages (logarithmic: f0 * f1 <= 0; hyperbolic: a zero frequency).
+ * klmi_chirp_render = update() x n_blocks -> float64[count][n_blocks*256]. */
+typedef enum {
+    KLMI_CHIRP_LINEAR = 0,
+    KLMI_CHIRP_QUADRATIC = 1,
+    KLMI_CHIRP_LOGARITHMIC = 2,
+    KLMI_CHIRP_HYPERBOLIC = 3
+} klmi_chirp_method;
+int klmi_chirp_create(klmi_ctx *ctx, int count, const double *start_frequency,
+                      const double *duration, const double *end_frequency,
+                      const int32_t *method, const int32_t *wave, klmi_chirp **out);
+int klmi_chirp_destroy(klmi_chirp *chirp);
+int klmi_chirp_reset(klmi_chirp *chirp, int first, int count);
+int klmi_chirp_render(klmi_chirp *chirp, int n_blocks, double *host_out);
+int klmi_chirp_state_get(klmi_chirp *chirp, double *host_t /* [count][256] */);
 
 #ifdef __cplusplus
 }

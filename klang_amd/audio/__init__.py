@@ -1,6 +1,6 @@
 """Audio blocks: the public names of the reference's klang.audio that lie on
 the DSP hot path (klang/audio/__init__.py star-imports)."""
-from klang_amd.audio.signals import (FmOscillator, Lfo, Oscillator, Phasor, PwmOscillator, WAVE_FUNCTIONS,
+from klang_amd.audio.signals import (Chirper, FmOscillator, Lfo, Oscillator, Phasor, PwmOscillator, WAVE_FUNCTIONS,
                                      sample_phase, sawtooth, sine, square, triangle)
 from klang_amd.audio.envelopes import ADSR, AR, D, R, Envelope
 from klang_amd.audio.filtering import (BackwardCombFilter, EchoFilter, Filter,
@@ -13,7 +13,7 @@ from klang_amd.audio.synthesizer import (Kick, MonophonicSynthesizer, NoteSchedu
                                          PolyphonicSynthesizer, Synthesizer)
 from klang_amd.audio.engine import Adc, Dac, run_audio_engine, write_wave
 
-__all__ = ['FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscillator', 'WAVE_FUNCTIONS', 'sample_phase',
+__all__ = ['Chirper', 'FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscillator', 'WAVE_FUNCTIONS', 'sample_phase',
            'sawtooth', 'sine', 'square', 'triangle', 'ADSR', 'AR', 'D', 'R', 'Envelope',
            'BackwardCombFilter', 'EchoFilter', 'Filter', 'ForwardCombFilter', 'Reverb', 'Mixer',
            'StereoMixer', 'Voice', 'Kick', 'MonophonicSynthesizer', 'NoteScheduler', 'PolyphonicSynthesizer',

@@ -206,3 +206,54 @@ class PwmOscillator(Phasor):
 
     def _ctor_kwargs(self):
         return dict(super()._ctor_kwargs(), dutyCycle=self.dutyCycle.value)
+
+
+def chirp_phase(t, f0, t1, f1, method='linear'):
+    """Phase of a frequency sweep from f0 (at t = 0) to f1 (at t = t1): scipy.signal's
+    `_chirp_phase` with vertex_zero=True, which the reference imports
+    (klang/audio/oscillators.py:3, 298-304), restated so that no private SciPy name is needed."""
+    t = np.asarray(t)
+    f0, t1, f1 = float(f0), float(t1), float(f1)
+    if method in ('linear', 'lin', 'li'):
+        beta = (f1 - f0) / t1
+        return 2 * np.pi * (f0 * t + 0.5 * beta * t * t)
+    if method in ('quadratic', 'quad', 'q'):
+        beta = (f1 - f0) / (t1 ** 2)
+        return 2 * np.pi * (f0 * t + beta * t ** 3 / 3)
+    if method in ('logarithmic', 'log', 'lo'):
+        if f0 * f1 <= 0.0:
+            raise ValueError('For a logarithmic chirp, f0 and f1 must be nonzero and have the '
+                             'same sign.')
+        if f0 == f1:
+            return 2 * np.pi * f0 * t
+        beta = t1 / np.log(f1 / f0)
+        return 2 * np.pi * beta * f0 * (np.power(f1 / f0, t / t1) - 1.0)
+    if method in ('hyperbolic', 'hyp'):
+        if f0 == 0 or f1 == 0:
+            raise ValueError('For a hyperbolic chirp, f0 and f1 must be nonzero.')
+        if f0 == f1:
+            return 2 * np.pi * f0 * t
+        sing = -f1 * t1 / (f0 - f1)
+        return 2 * np.pi * (-sing * f0) * np.log(np.abs(1 - t / sing))
+    raise ValueError("method must be 'linear', 'quadratic', 'logarithmic', or 'hyperbolic', but "
+                     'a value of %r was given.' % (method,))
+
+
+class Chirper(Block):
+    """Chirp oscillator: frequency ascends or descends from startFrequency to endFrequency
+    over `duration` and keeps going (oscillators.py:280-308)."""
+
+    def __init__(self, startFrequency, duration, endFrequency, method='linear', wave_func=sine):
+        super().__init__(nOutputs=1)
+        self.startFrequency, self.duration, self.endFrequency = startFrequency, duration, endFrequency
+        self.method, self.wave_func = method, wave_func
+        self.t = get_time(BUFFER_SIZE).copy()
+
+    def reset(self):
+        self.t = get_time(BUFFER_SIZE).copy()
+
+    def update(self):
+        phase = chirp_phase(self.t, self.startFrequency, self.duration, self.endFrequency,
+                            self.method)
+        self.output.set_value(self.wave_func(phase))
+        self.t += DT * BUFFER_SIZE

@@ -141,4 +141,51 @@ __global__ __launch_bounds__(kBlock) void kick_kernel(int count, int n_blocks,
         time_state[k] = time;
 }
 
+// klang.audio.oscillators.Chirper x count (oscillators.py:280-308) over scipy.signal's
+// _chirp_phase (vertex_zero=True).  One workgroup of 256 threads = one chirper, thread =
+// sample position; every thread owns one element of the chirper's time vector, which gains
+// DT * BUFFER_SIZE per buffer (a float64 running sum per element, as `self.t += ...`).
+// par: [3][count] startFrequency, duration, endFrequency; kind: [2][count] method, wave;
+// t_state: [count][256]; out: [count][n_blocks*256] float64.
+enum ChirpMethod : int { CHIRP_LINEAR = 0, CHIRP_QUADRATIC, CHIRP_LOGARITHMIC, CHIRP_HYPERBOLIC };
+
+__global__ __launch_bounds__(kBlock) void chirp_kernel(int count, int n_blocks,
+                                                       const double *__restrict__ par,
+                                                       const int32_t *__restrict__ kind,
+                                                       double *__restrict__ t_state,
+                                                       double *__restrict__ out)
+{
+    const int k = blockIdx.x, i = threadIdx.x;
+    const double f0 = par[k], t1 = par[count + k], f1 = par[2 * (size_t)count + k];
+    const int method = kind[k], wave = kind[count + k];
+    double t = t_state[(size_t)k * kBlock + i];
+    for (int b = 0; b < n_blocks; ++b) {
+        double p;
+        if (method == CHIRP_QUADRATIC) {
+            const double beta = (f1 - f0) / (t1 * t1);
+            p = kTau * (f0 * t + beta * pow(t, 3.) / 3.);
+        } else if (method == CHIRP_LOGARITHMIC) {
+            if (f0 == f1) {
+                p = kTau * f0 * t;
+            } else {
+                const double beta = t1 / log(f1 / f0);
+                p = kTau * beta * f0 * (pow(f1 / f0, t / t1) - 1.0);
+            }
+        } else if (method == CHIRP_HYPERBOLIC) {
+            if (f0 == f1) {
+                p = kTau * f0 * t;
+            } else {
+                const double sing = -f1 * t1 / (f0 - f1);
+                p = kTau * (-sing * f0) * log(fabs(1 - t / sing));
+            }
+        } else {
+            const double beta = (f1 - f0) / t1;
+            p = kTau * (f0 * t + 0.5 * beta * t * t);
+        }
+        out[((size_t)k * n_blocks + b) * kBlock + i] = wave_eval_any(wave, p, kPi);
+        t = t + kDt * kBlock;   // oscillators.py:308
+    }
+    t_state[(size_t)k * kBlock + i] = t;
+}
+
 }  // namespace klmi

@@ -2285,3 +2285,129 @@ extern "C" int klmi_kick_state_get(klmi_kick *k, double *host_time, double *host
                           hipMemcpyDeviceToHost));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// chirp oscillators (klang.audio.oscillators.Chirper x count)
+// ---------------------------------------------------------------------------------
+struct klmi_chirp {
+    klmi_ctx *ctx = nullptr;
+    int count = 0;
+    DevBuf<double> par, t, out;
+    DevBuf<int32_t> kind;
+};
+
+static int chirp_reset_range(klmi_chirp *c, int first, int count)
+{
+    std::vector<double> t((size_t)count * kBlock);
+    for (int k = 0; k < count; ++k)
+        for (int i = 0; i < kBlock; ++i)
+            t[(size_t)k * kBlock + i] = kDt * (double)i;  // helpers.py:30 get_time
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    HIP_TRY(hipMemcpy(c->t.p + (size_t)first * kBlock, t.data(), sizeof(double) * t.size(),
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int klmi_chirp_create(klmi_ctx *ctx, int count, const double *start_frequency,
+                                 const double *duration, const double *end_frequency,
+                                 const int32_t *method, const int32_t *wave, klmi_chirp **out)
+{
+    TRY(use(ctx));
+    if (!out || count <= 0 || !start_frequency || !duration || !end_frequency || !method || !wave)
+        return fail(KLMI_E_ARG, "klmi_chirp_create: bad argument");
+    for (int k = 0; k < count; ++k) {
+        const double f0 = start_frequency[k], f1 = end_frequency[k];
+        if (method[k] < KLMI_CHIRP_LINEAR || method[k] > KLMI_CHIRP_HYPERBOLIC)
+            return fail(KLMI_E_ARG, "method must be 'linear', 'quadratic', 'logarithmic', or "
+                                    "'hyperbolic', but a value of %d was given.", method[k]);
+        if (wave[k] < KLMI_WAVE_SINE || wave[k] > KLMI_WAVE_TRIANGLE)
+            return fail(KLMI_E_ARG, "klmi_chirp_create: wave id %d (sine, square, sawtooth, "
+                                    "triangle are 0..3)", wave[k]);
+        if (method[k] == KLMI_CHIRP_LOGARITHMIC && f0 * f1 <= 0.0)
+            return fail(KLMI_E_ARG, "For a logarithmic chirp, f0 and f1 must be nonzero and have "
+                                    "the same sign.");
+        if (method[k] == KLMI_CHIRP_HYPERBOLIC && (f0 == 0 || f1 == 0))
+            return fail(KLMI_E_ARG, "For a hyperbolic chirp, f0 and f1 must be nonzero.");
+    }
+    klmi_chirp *c = new klmi_chirp;
+    c->ctx = ctx;
+    c->count = count;
+    std::vector<double> par((size_t)3 * count);
+    std::vector<int32_t> kind((size_t)2 * count);
+    for (int k = 0; k < count; ++k) {
+        par[k] = start_frequency[k];
+        par[(size_t)count + k] = duration[k];
+        par[2 * (size_t)count + k] = end_frequency[k];
+        kind[k] = method[k];
+        kind[(size_t)count + k] = wave[k];
+    }
+    hipError_t e = c->par.alloc(par.size());
+    if (e == hipSuccess) e = c->kind.alloc(kind.size());
+    if (e == hipSuccess) e = c->t.alloc((size_t)count * kBlock);
+    if (e == hipSuccess)
+        e = hipMemcpy(c->par.p, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(c->kind.p, kind.data(), sizeof(int32_t) * kind.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(KLMI_E_MEMORY, "klmi_chirp_create: %s", hipGetErrorString(e));
+    }
+    const int rc = chirp_reset_range(c, 0, count);
+    if (rc != 0) {
+        delete c;
+        return rc;
+    }
+    ctx->live_objects++;
+    *out = c;
+    return 0;
+}
+
+extern "C" int klmi_chirp_destroy(klmi_chirp *chirp)
+{
+    if (!chirp)
+        return 0;
+    (void)hipSetDevice(chirp->ctx->device);
+    (void)hipStreamSynchronize(chirp->ctx->stream);
+    chirp->ctx->live_objects--;
+    delete chirp;
+    return 0;
+}
+
+extern "C" int klmi_chirp_reset(klmi_chirp *c, int first, int count)
+{
+    if (!c)
+        return fail(KLMI_E_ARG, "klmi_chirp_reset: null chirp");
+    if (first < 0 || count < 0 || (long)first + count > c->count)
+        return fail(KLMI_E_ARG, "klmi_chirp_reset: range [%d, %d) outside %d chirpers", first,
+                    first + count, c->count);
+    TRY(use(c->ctx));
+    return count ? chirp_reset_range(c, first, count) : 0;
+}
+
+extern "C" int klmi_chirp_render(klmi_chirp *c, int n_blocks, double *host_out)
+{
+    if (!c || !host_out)
+        return fail(KLMI_E_ARG, "klmi_chirp_render: null argument");
+    if (n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_chirp_render: n_blocks must be positive, got %d", n_blocks);
+    TRY(use(c->ctx));
+    hipStream_t st = c->ctx->stream;
+    const size_t len = (size_t)c->count * n_blocks * kBlock;
+    HIP_TRY(c->out.reserve(len));
+    hipLaunchKernelGGL(chirp_kernel, dim3(c->count), dim3(kBlock), 0, st, c->count, n_blocks,
+                       c->par.p, c->kind.p, c->t.p, c->out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(host_out, c->out.p, sizeof(double) * len, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int klmi_chirp_state_get(klmi_chirp *c, double *host_t)
+{
+    if (!c || !host_t)
+        return fail(KLMI_E_ARG, "klmi_chirp_state_get: null argument");
+    TRY(use(c->ctx));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    HIP_TRY(hipMemcpy(host_t, c->t.p, sizeof(double) * c->count * kBlock, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -43,7 +43,7 @@ from klang_amd.audio.effects import (Bitcrusher, Delay, Gain, OctaveDistortion, 
 from klang_amd.audio.envelopes import EnvelopeBase
 from klang_amd.audio.filtering import BackwardCombFilter, Filter, Reverb
 from klang_amd.audio.mixers import Mixer, StereoMixer
-from klang_amd.audio.signals import (BUFFER_SIZE, SCALAR, FmOscillator, Lfo, Oscillator, Phasor,
+from klang_amd.audio.signals import (BUFFER_SIZE, SCALAR, Chirper, FmOscillator, Lfo, Oscillator, Phasor,
                                       PwmOscillator, WAVE_IDS)
 from klang_amd.audio.synthesizer import (Kick, MonophonicSynthesizer, PolyphonicSynthesizer,
                                          Synthesizer)
@@ -59,7 +59,8 @@ EFFECT_KINDS = {Filter: native.FX_FILTER, Gain: native.FX_GAIN, Transformer: nat
                 Subsampler: native.FX_SUBSAMPLE, Bitcrusher: native.FX_BITCRUSH,
                 RingModulator: native.FX_RINGMOD}
 ONE_PER_CHAIN = (Filter, Tremolo, Delay, Subsampler, RingModulator)   # stateful stages
-HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer, Synthesizer, Kick) + tuple(
+HOT_PATH_TYPES = (Phasor, EnvelopeBase, Voice, Filter, Reverb, Mixer, Synthesizer, Kick,
+                  Chirper) + tuple(
     t for t in EFFECT_KINDS if t is not Filter)
 
 
@@ -553,6 +554,49 @@ class GpuKick(Block):
         return 'GpuKick(%s)' % self.kick
 
 
+class GpuChirper(Block):
+    """One Chirper block evaluated on the device (klmi_chirp_*, count 1); the chirper's own
+    Output carries the result.  A chirper has no inputs, so it may render ahead."""
+
+    def __init__(self, chirper, ctx=None):
+        super().__init__()
+        self.chirper = chirper
+        if chirper.wave_func not in WAVE_IDS or WAVE_IDS[chirper.wave_func] > native.WAVE_TRIANGLE:
+            raise NotFusable('%s: wave function %r has no device twin' % (chirper, chirper.wave_func))
+        if np.any(chirper.t != Chirper(1., 1., 1.).t):
+            raise NotFusable('%s has already played on the host' % chirper)
+        try:
+            self.batch = native.ChirpBatch(ctx or native.default_context(), [chirper.startFrequency],
+                                           [chirper.duration], [chirper.endFrequency],
+                                           chirper.method, WAVE_IDS[chirper.wave_func])
+        except native.NativeError as err:
+            raise ValueError(str(err)) from None      # scipy's ValueErrors for bad sweeps
+        self.lookahead, self.remaining = 1, None
+        self._ready = []
+
+    def update(self):
+        if not self._ready:
+            ahead = max(1, int(self.lookahead))
+            if self.remaining is not None:
+                ahead = max(1, min(ahead, int(self.remaining)))
+            self._ready = list(self.batch.render(ahead)[0].reshape(ahead, BUFFER_SIZE))[::-1]
+        if self.remaining is not None:
+            self.remaining -= 1
+        self.chirper.output.set_value(self._ready.pop())
+
+    def sync_host_blocks(self):
+        # buffers rendered ahead but never played do not count
+        self.chirper.t = (self.batch.time_vectors()[0]
+                          - len(self._ready) * (BUFFER_SIZE / 44100.) if self._ready
+                          else self.batch.time_vectors()[0])
+
+    def close(self):
+        self.batch.close()
+
+    def __str__(self):
+        return 'GpuChirper(%s)' % self.chirper
+
+
 def _flat(order):
     for blk in order:
         yield blk
@@ -638,9 +682,9 @@ def compile_order(exec_order, ctx=None, strict=True):
         fused_blocks.add(sink)
         banks_at[sink] = bank
     for blk in exec_order:
-        if isinstance(blk, Kick):
+        if isinstance(blk, (Kick, Chirper)):
             try:
-                banks_at[blk] = GpuKick(blk, ctx)
+                banks_at[blk] = GpuKick(blk, ctx) if isinstance(blk, Kick) else GpuChirper(blk, ctx)
             except NotFusable as err:
                 errors.append(str(err))
     new_order = []

@@ -69,6 +69,8 @@ EXPORTS = [
     'klmi_comb_destroy', 'klmi_comb_set_alpha', 'klmi_comb_filter',
     'klmi_kick_create', 'klmi_kick_destroy', 'klmi_kick_set', 'klmi_kick_trigger',
     'klmi_kick_render', 'klmi_kick_state_get',
+    'klmi_chirp_create', 'klmi_chirp_destroy', 'klmi_chirp_reset', 'klmi_chirp_render',
+    'klmi_chirp_state_get',
 ]
 
 
@@ -155,6 +157,11 @@ def load():
     L.klmi_kick_trigger.argtypes = [_vp, _vp, _vp, C.c_size_t]
     L.klmi_kick_render.argtypes = [_vp, C.c_int, _dp]
     L.klmi_kick_state_get.argtypes = [_vp, _dp, _dp]
+    L.klmi_chirp_create.argtypes = [_vp, C.c_int, _dp, _dp, _dp, _ip, _ip, C.POINTER(_vp)]
+    L.klmi_chirp_destroy.argtypes = [_vp]
+    L.klmi_chirp_reset.argtypes = [_vp, C.c_int, C.c_int]
+    L.klmi_chirp_render.argtypes = [_vp, C.c_int, _dp]
+    L.klmi_chirp_state_get.argtypes = [_vp, _dp]
     _lib = L
     return L
 
@@ -585,3 +592,57 @@ class KickBatch:
         time, phase = np.empty(self.count), np.empty((self.count, BUFFER_SIZE))
         _check(load().klmi_kick_state_get(self._h, _p(time), _p(phase)))
         return time, phase
+
+
+CHIRP_METHODS = {'linear': 0, 'lin': 0, 'li': 0, 'quadratic': 1, 'quad': 1, 'q': 1,
+                 'logarithmic': 2, 'log': 2, 'lo': 2, 'hyperbolic': 3, 'hyp': 3}
+
+
+class ChirpBatch:
+    """count x klang.audio.oscillators.Chirper on the device (klmi_chirp_*).  Arguments are
+    arrays of `count` values; methods by scipy's names; waves as klmi_wave ids."""
+
+    def __init__(self, ctx, start_frequency, duration, end_frequency, method='linear',
+                 wave=WAVE_SINE):
+        f0 = _f64(np.atleast_1d(start_frequency))
+        self.count = f0.size
+        t1 = _f64(np.broadcast_to(duration, f0.shape))
+        f1 = _f64(np.broadcast_to(end_frequency, f0.shape))
+        methods = np.broadcast_to(np.atleast_1d(method), f0.shape)
+        for m in methods:
+            if m not in CHIRP_METHODS:   # scipy's message
+                raise ValueError("method must be 'linear', 'quadratic', 'logarithmic', or "
+                                 "'hyperbolic', but a value of %r was given." % (m,))
+        mid = np.ascontiguousarray([CHIRP_METHODS[m] for m in methods], dtype=np.int32)
+        wid = np.ascontiguousarray(np.broadcast_to(wave, f0.shape), dtype=np.int32)
+        self.ctx = ctx
+        self._h = _vp()
+        _check(load().klmi_chirp_create(ctx._h, self.count, _p(f0), _p(t1), _p(f1),
+                                        mid.ctypes.data_as(_ip), wid.ctypes.data_as(_ip),
+                                        C.byref(self._h)))
+        _live_objects.add(self)
+        ctx._children.add(self)
+
+    def close(self):
+        if self._h:
+            load().klmi_chirp_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, first=0, count=None):
+        _check(load().klmi_chirp_reset(self._h, first, self.count - first if count is None else count))
+
+    def render(self, n_blocks):
+        out = np.empty((self.count, int(n_blocks) * BUFFER_SIZE))
+        _check(load().klmi_chirp_render(self._h, int(n_blocks), _p(out)))
+        return out
+
+    def time_vectors(self):
+        t = np.empty((self.count, BUFFER_SIZE))
+        _check(load().klmi_chirp_state_get(self._h, _p(t)))
+        return t

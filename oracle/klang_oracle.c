@@ -923,6 +923,60 @@ void ko_kick_block(ko_kick *k, int trigger, double *out)
     k->current_time = k->current_time + dt * KO_BUFFER_SIZE;
 }
 
+/* ------------------------------------------------------------------------ */
+/* oscillators.py:280-308 Chirper over scipy.signal's _chirp_phase (scipy 1.15.3
+ * scipy/signal/_waveforms.py, vertex_zero=True; un-vendored: restated from its source as
+ * installed in the survey container).  The chirper's time vector starts as T and gains
+ * DT * BUFFER_SIZE per element and buffer (a float64 running sum per element). */
+void ko_chirp_block(ko_chirper *c, double *out)
+{
+    const double f0 = c->f0, t1 = c->t1, f1 = c->f1;
+    double phase[KO_BUFFER_SIZE];
+    for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+        const double t = c->t[i];
+        double p;
+        switch (c->method) {
+        case KO_CHIRP_QUADRATIC: {
+            const double beta = (f1 - f0) / (t1 * t1);       /* t1 ** 2 */
+            p = KO_TAU * (f0 * t + beta * pow(t, 3.) / 3.);
+            break;
+        }
+        case KO_CHIRP_LOGARITHMIC:
+            if (f0 == f1) {
+                p = KO_TAU * f0 * t;
+            } else {
+                const double beta = t1 / log(f1 / f0);
+                p = KO_TAU * beta * f0 * (pow(f1 / f0, t / t1) - 1.0);
+            }
+            break;
+        case KO_CHIRP_HYPERBOLIC:
+            if (f0 == f1) {
+                p = KO_TAU * f0 * t;
+            } else {
+                const double sing = -f1 * t1 / (f0 - f1);
+                p = KO_TAU * (-sing * f0) * log(fabs(1 - t / sing));
+            }
+            break;
+        default: { /* linear */
+            const double beta = (f1 - f0) / t1;
+            p = KO_TAU * (f0 * t + 0.5 * beta * t * t);
+            break;
+        }
+        }
+        phase[i] = p;
+    }
+    ko_wave(c->wave, phase, KO_BUFFER_SIZE, .5, out);
+    const double step = (1. / KO_SAMPLING_RATE) * KO_BUFFER_SIZE; /* oscillators.py:308 */
+    for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+        c->t[i] = c->t[i] + step;
+}
+
+void ko_chirp_reset(ko_chirper *c)
+{
+    for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+        c->t[i] = (1. / KO_SAMPLING_RATE) * (double)i; /* helpers.py:30 */
+}
+
 int ko_max_threads(void)
 {
 #ifdef _OPENMP

@@ -218,6 +218,17 @@ typedef struct {
 } ko_kick;
 void ko_kick_block(ko_kick *kick, int trigger, double *out /* 256 */);
 
+/* ---- oscillators.py Chirper ------------------------------------------------ */
+enum { KO_CHIRP_LINEAR = 0, KO_CHIRP_QUADRATIC, KO_CHIRP_LOGARITHMIC, KO_CHIRP_HYPERBOLIC };
+typedef struct {
+    double f0, t1, f1; /* startFrequency, duration, endFrequency */
+    int method;        /* KO_CHIRP_* */
+    int wave;          /* ko_wave */
+    double t[KO_BUFFER_SIZE];
+} ko_chirper;
+void ko_chirp_reset(ko_chirper *c);
+void ko_chirp_block(ko_chirper *c, double *out /* 256 */);
+
 int ko_max_threads(void);
 
 #ifdef __cplusplus

@@ -58,6 +58,11 @@ NOTE_DTYPE = np.dtype([('instrument', '<u4'), ('block', '<u4'), ('pitch', '<i4')
                        ('reserved', '<u4'), ('velocity', '<f8'), ('frequency', '<f8')])
 
 
+class Chirper(C.Structure):
+    _fields_ = [('f0', C.c_double), ('t1', C.c_double), ('f1', C.c_double), ('method', C.c_int),
+                ('wave', C.c_int), ('t', C.c_double * BUFFER_SIZE)]
+
+
 class Kick(C.Structure):
     _fields_ = [('frequency', C.c_double), ('decay', C.c_double), ('intensity', C.c_double),
                 ('pitch_decay', C.c_double), ('current_time', C.c_double),
@@ -148,6 +153,8 @@ def lib():
         L.ko_bounce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                                 C.c_void_p, C.c_void_p]
         L.ko_kick_block.argtypes = [C.POINTER(Kick), C.c_int, _dp]
+        L.ko_chirp_reset.argtypes = [C.POINTER(Chirper)]
+        L.ko_chirp_block.argtypes = [C.POINTER(Chirper), _dp]
         L.ko_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -505,6 +512,27 @@ def bounce(bus, duration, fadeout=0., want_pcm=True):
     peak = lib().ko_bounce(bus.ctypes.data, n_blocks, channels, float(duration), float(fadeout),
                            frames.ctypes.data, pcm.ctypes.data if want_pcm else None)
     return frames, pcm, float(peak)
+
+
+CHIRP_METHODS = {'linear': 0, 'quadratic': 1, 'logarithmic': 2, 'hyperbolic': 3}
+
+
+class OracleChirper:
+    """klang.audio.oscillators.Chirper (oscillators.py:280-308)."""
+
+    def __init__(self, start_frequency, duration, end_frequency, method='linear', wave_name='sine'):
+        self.c = Chirper(start_frequency, duration, end_frequency, CHIRP_METHODS[method],
+                         WAVE_IDS[wave_name])
+        lib().ko_chirp_reset(C.byref(self.c))
+
+    def block(self):
+        out = np.empty(BUFFER_SIZE)
+        lib().ko_chirp_block(C.byref(self.c), _p(out))
+        return out
+
+    @property
+    def t(self):
+        return np.array(self.c.t[:])
 
 
 class OracleKick:

@@ -217,3 +217,63 @@ def test_many_kicks_vs_oracle(hip, ctx, oracle):
         want = np.concatenate([kick.block(hits[i, b]) for b in range(nb)])
         assert np.abs(got[i] - want).max() <= 1e-11
     batch.close()
+
+
+# ---- Chirper (oscillators.py:280-308) --------------------------------------------------------
+CHIRPS = [('linear_sine', (100., .4, 2000., 'linear'), 'sine', 1e-12),
+          ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth', 0.),
+          ('linear_square', (30., .5, 900., 'linear'), 'square', 0.),
+          ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine', 1e-9),
+          ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine', 1e-9),
+          ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine', 1e-9)]
+
+
+def test_chirp_batch_vs_reference(hip, ctx, golden):
+    """All six fixtures as ONE batch, rendered in three calls.  Linear sweeps are plain
+    float64 arithmetic: non-sine waves bit-exact; pow / log sweeps differ by libm ulps inside
+    a phase of a few thousand radians."""
+    g = golden('chirper')
+    waves = {'sine': hip.WAVE_SINE, 'sawtooth': hip.WAVE_SAWTOOTH, 'square': hip.WAVE_SQUARE}
+    batch = hip.ChirpBatch(ctx, [c[1][0] for c in CHIRPS], [c[1][1] for c in CHIRPS],
+                           [c[1][2] for c in CHIRPS], [c[1][3] for c in CHIRPS],
+                           [waves[c[2]] for c in CHIRPS])
+    out = np.concatenate([batch.render(k) for k in (1, 9, 30)], axis=1)
+    t = batch.time_vectors()
+    for i, (name, _, _, tol) in enumerate(CHIRPS):
+        want = g[name].ravel()
+        if tol:
+            assert np.abs(out[i] - want).max() <= tol, name
+        else:
+            np.testing.assert_array_equal(out[i], want)
+        np.testing.assert_array_equal(t[i], g[name + '_t'])
+    batch.reset(1, 1)
+    np.testing.assert_array_equal(batch.render(1)[1], g['linear_saw'][0])
+    batch.close()
+    with pytest.raises(hip.NativeError) as e:
+        hip.ChirpBatch(ctx, [100.], [1.], [-100.], 'logarithmic')
+    assert 'same sign' in str(e.value)
+    with pytest.raises(hip.NativeError):
+        hip.ChirpBatch(ctx, [0.], [1.], [100.], 'hyperbolic')
+    with pytest.raises(ValueError):
+        hip.ChirpBatch(ctx, [10.], [1.], [100.], 'cubic')
+
+
+def test_chirper_and_kick_through_the_api(hip):
+    """A Chirper and a Kick into one Mixer: both blocks run on the device, the mixer takes
+    their outputs as external voices; equal to the host evaluation."""
+    from klang_amd.audio import Chirper, Dac, Kick, Mixer, sawtooth
+    from klang_amd.klang import run_klang
+    from klang_amd.messages import Note
+
+    def build():
+        kick = Kick(frequency=60., decay=.3)
+        kick.input.push(Note(36))
+        mixer = Mixer()
+        mixer += Chirper(200., .2, 3000., wave_func=sawtooth)
+        mixer += kick
+        return mixer | Dac()
+    dur = 30 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur))
+    want = np.concatenate(run_klang(build(), offline=True, duration=dur, backend='host'))
+    assert got.shape == want.shape and np.abs(want).max() > .3
+    assert np.abs(got - want).max() <= 1e-6

@@ -411,3 +411,41 @@ def test_find_fusable_synthesizers():
     groups, errors = fusion.find_fusable(determine_execution_order([syn | fil | Dac()]))
     assert not errors and [g[0] for g in groups] == [syn, fil]
     assert groups[1][1][0].external is syn.output and groups[1][1][0].filter is fil
+
+
+def test_host_chirper_and_kick_vs_golden(golden):
+    """Chirper (oscillators.py:280-308, scipy's _chirp_phase restated) and Kick
+    (synthesizer.py:253-283) as host blocks: the same NumPy operations as the reference."""
+    from klang_amd.audio import Chirper, Kick, sawtooth, sine, square
+    from klang_amd.messages import Note
+    g = golden('chirper')
+    for name, args, wave in (('linear_sine', (100., .4, 2000., 'linear'), sine),
+                             ('linear_saw', (2000., .3, 50., 'linear'), sawtooth),
+                             ('linear_square', (30., .5, 900., 'linear'), square),
+                             ('quadratic_sine', (100., .4, 2000., 'quadratic'), sine),
+                             ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), sine),
+                             ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), sine)):
+        ch = Chirper(*args, wave_func=wave)
+        out = []
+        for _ in range(len(g[name])):
+            ch.update()
+            out.append(np.array(ch.output.value))
+        np.testing.assert_array_equal(np.array(out), g[name])
+        np.testing.assert_array_equal(ch.t, g[name + '_t'])
+        ch.reset()
+        assert ch.t[0] == 0. and ch.t[1] == 1. / 44100
+    with pytest.raises(ValueError):
+        Chirper(100., 1., -100., 'logarithmic').update()
+    with pytest.raises(ValueError):
+        Chirper(100., 1., 200., 'cubic').update()
+    s = golden('synthesizer')
+    kick = Kick()
+    hits = {0: Note(36), 30: Note(36, 0.), 70: Note(36)}
+    out = []
+    for b in range(100):
+        if b in hits:
+            kick.input.push(hits[b])
+        kick.update()
+        out.append(np.array(kick.output.value))
+    np.testing.assert_array_equal(np.array(out), s['kick_default_out'])
+    np.testing.assert_array_equal(np.r_[kick.currentTime, kick.currentPhase], s['kick_default_final'])

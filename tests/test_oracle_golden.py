@@ -636,3 +636,23 @@ def test_kick_drum(oracle, golden, name, kw, triggers):
     assert np.abs(want).max() > .5
     assert abs(kick.current_time - g[name + '_final'][0]) <= 1e-12
     np.testing.assert_allclose(kick.current_phase, g[name + '_final'][1:], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('name,args,wave,tol', [
+    ('linear_sine', (100., .4, 2000., 'linear'), 'sine', 1e-12),   # exact phase, sine ulps
+    ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth', 0.),
+    ('linear_square', (30., .5, 900., 'linear'), 'square', 0.),
+    ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine', 1e-9),      # pow / log of another
+    ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine', 1e-9),  # libm inside a phase
+    ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine', 1e-9),    # of a few thousand rad
+])
+def test_chirper(oracle, golden, name, args, wave, tol):
+    g = golden('chirper')
+    want = g[name]
+    ch = oracle.OracleChirper(*args, wave_name=wave)
+    got = np.array([ch.block() for _ in range(len(want))])
+    if tol:
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    else:
+        eq(got, want)
+    eq(ch.t, g[name + '_t'])

@@ -119,6 +119,23 @@ def main():
          lfo_scale_offset=np.array([lfo_s.scale, lfo_s.offset, lfo_v.scale, lfo_v.offset]),
          **wav)
 
+    # ---- Chirper (oscillators.py:280-308) over scipy's _chirp_phase ----------
+    chirp = {}
+    for name, args, wname in (('linear_sine', (100., .4, 2000., 'linear'), 'sine'),
+                              ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth'),
+                              ('linear_square', (30., .5, 900., 'linear'), 'square'),
+                              ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine'),
+                              ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine'),
+                              ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine')):
+        ch = OSC.Chirper(*args, wave_func=W.WAVE_FUNCTIONS[wname])
+        blocks = []
+        for b in range(40):
+            ch.update()
+            blocks.append(np.array(ch.output.value, dtype=float))
+        chirp[name] = np.array(blocks)
+        chirp[name + '_t'] = ch.t.copy()
+    save('chirper', **chirp)
+
     # ---- Oscillator over 64 blocks (oscillators.py:111-140) --------------
     out = {}
     for f in (440., 19999.):
