@@ -68,8 +68,9 @@ def config2(ctx):
 
 def config3_materialised(ctx):
     import torch
-    n, n_blocks = 65536, 64
-    patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=n_blocks, off_base=10, off_span=20)
+    n, n_blocks = 65536, int(os.environ.get('KLANG_BENCH_BLOCKS', '64'))   # override: experiments
+    patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=n_blocks, off_base=min(10, n_blocks // 2),
+                                         off_span=max(1, min(20, n_blocks // 3)))
     bank, ev = bank_for(ctx, patch)
     bank.events(ev)
     out = torch.empty((n, n_blocks * B), dtype=torch.float32, device='cuda')
