@@ -63,3 +63,17 @@ def hip():
     if not has_gpu():
         pytest.skip('no GPU in this environment')
     return native
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Per-block-type parity table of this run (float32 output vs the reference's float64)."""
+    import json
+    from tests.helpers import REPORT
+    if not REPORT:
+        return
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    table = {k: REPORT[k] for k in sorted(REPORT)}
+    with open(os.path.join(out, 'parity_report.json'), 'w') as fh:
+        json.dump({'bound': 1e-5, 'unit': 'max abs error, float32 output vs reference float64',
+                   'exit_status': int(exitstatus), 'block_types': table}, fh, indent=1)

@@ -70,3 +70,14 @@ def bounce_signals(name, n_blocks, channels):
     'bounce' fixtures (same recipe; the fixture stores a checksum)."""
     r = np.random.default_rng(len(name))
     return (2. * r.random((n_blocks, channels, B)) - 1.) * np.linspace(.2, 1.3, n_blocks)[:, None, None]
+
+
+# ---- parity report: max abs error of the float32 output vs the reference's float64, per block
+# type (north_star).  The GPU tests call report(); tests/conftest.py writes the table to
+# gpurun_out/parity_report.json when the session ends.
+REPORT = {}
+
+
+def report(block_type, err):
+    REPORT[block_type] = max(REPORT.get(block_type, 0.), float(err))
+    return err

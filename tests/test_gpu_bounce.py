@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from klang_amd import patches as P
-from tests.helpers import B, bounce_signals, hip_bank_from_patch
+from tests.helpers import B, bounce_signals, hip_bank_from_patch, report
 
 pytestmark = pytest.mark.gpu
 
@@ -43,6 +43,7 @@ def test_bounce_vs_reference_wav(hip, ctx, golden, name, ch):
     bank = external_bank(hip, ctx, sig)
     frames, pcm, peak = bank.bounce(duration, fadeout)
     assert frames.shape == (n_blocks * B, ch)
+    report('bounce: int16 samples (steps)', np.abs(pcm.astype(int) - want.astype(int)).max())
     np.testing.assert_array_equal(pcm, want)
     assert peak == np.abs(frames).max()
     bank.close()

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from klang_amd import patches as P
-from tests.helpers import B, library_table
+from tests.helpers import B, library_table, report
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def test_effect_stage_vs_reference(hip, ctx, golden, key, stage, n_blocks, tol):
     # the committing render in two launches carries the stage state and the delay line
     k = n_blocks // 3
     mix = np.concatenate([bank.render(k), bank.render(n_blocks - k)])[:, 0, :]
-    assert np.abs(mix - want).max() <= 1e-5 * max(1., np.abs(want).max())
+    assert report('effect: ' + key.split('_')[0], np.abs(mix - want).max()) <= 1e-5 * max(1., np.abs(want).max())
     if key == 'tremolo':
         final = golden('effects')['tremolo_final']
         assert bank.get_state(hip.F_FX_STATE(0, 0))[0] == final[0]
@@ -85,7 +85,7 @@ def test_effect_chain_after_a_voice_vs_reference(hip, ctx, golden):
     got = bank.render_voices(30, f64=True)[0].reshape(30, B)
     assert np.abs(got - want).max() <= 1e-12     # closed-form vs scipy Butterworth row, tanh ulps
     mix = np.concatenate([bank.render(7), bank.render(23)])[:, 0, :]
-    assert np.abs(mix - want).max() <= 1e-5
+    assert report('effect chain after a voice', np.abs(mix - want).max()) <= 1e-5
 
 
 def test_effect_chains_vs_oracle_many_voices(hip, ctx, oracle):

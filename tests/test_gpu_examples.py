@@ -6,6 +6,8 @@ import wave
 import numpy as np
 import pytest
 
+from tests.helpers import report
+
 from klang_amd.klang import run_klang
 
 pytestmark = pytest.mark.gpu
@@ -29,5 +31,5 @@ def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, chan
     got, want = out['hip'][0], out['host'][0]
     assert got.shape == want.shape == (int(duration * 44100 // B) * B, channels)
     assert np.abs(want).max() > .02
-    assert np.abs(got - want).max() <= 1e-5
+    assert report('example patch: ' + name, np.abs(got - want).max()) <= 1e-5
     assert np.abs(out['hip'][1] - out['host'][1]).max() <= 2   # int16 steps after normalisation

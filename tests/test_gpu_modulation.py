@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from klang_amd import patches as P
-from tests.helpers import B, hip_bank_from_patch, library_table, oracle_bank_from_patch
+from tests.helpers import B, hip_bank_from_patch, library_table, oracle_bank_from_patch, report
 
 pytestmark = pytest.mark.gpu
 WAVES = ('sine', 'square', 'sawtooth', 'triangle')
@@ -41,7 +41,7 @@ def test_lfo_cutoff_vs_reference(hip, ctx, golden, wname):
     # the library's closed-form Butterworth table vs scipy's: <= 4e-15 relative per row
     assert np.abs(got - want).max() <= 1e-10
     mix = bank.render(40)[:, 0, :]
-    assert np.abs(mix - want).max() <= 1e-5
+    assert report('modulation: Lfo -> Filter.frequency', np.abs(mix - want).max()) <= 1e-5
     assert abs(bank.get_state(hip.F_LFO_PHASE)[0] - g['lfo_cutoff_%s_final_phase' % wname]) <= 1e-12
 
 
@@ -59,7 +59,7 @@ def test_fm_oscillator_vs_reference(hip, ctx, golden, wname):
         assert np.abs(got - want).max() <= 1e-14
     else:
         np.testing.assert_array_equal(got, want)
-    assert np.abs(bank.render(12)[:, 0, :] - want).max() <= 1e-5
+    assert report('modulation: FmOscillator', np.abs(bank.render(12)[:, 0, :] - want).max()) <= 1e-5
     np.testing.assert_array_equal(
         [bank.get_state(hip.F_PHASE)[0], bank.get_state(hip.F_MOD_PHASE)[0]],
         g['fm_%s_final_phases' % wname])
@@ -80,7 +80,7 @@ def test_frequency_modulated_by_audio_rate_lfo_vs_reference(hip, ctx, golden, wn
         assert np.abs(got - want).max() <= 1e-10
     else:
         np.testing.assert_array_equal(got, want)
-    assert np.abs(bank.render(12)[:, 0, :] - want).max() <= 1e-5
+    assert report('modulation: Lfo(256) -> frequency', np.abs(bank.render(12)[:, 0, :] - want).max()) <= 1e-5
     if wname != 'sine':
         np.testing.assert_array_equal(
             [bank.get_state(hip.F_PHASE)[0], bank.get_state(hip.F_MOD_PHASE)[0]],

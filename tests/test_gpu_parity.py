@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 
 from klang_amd import patches as P
-from tests.helpers import (B, hip_bank_from_patch, library_table, oracle_bank_from_patch,
-                           reference_table)
+from tests.helpers import (B, REPORT, hip_bank_from_patch, library_table, oracle_bank_from_patch,
+                           reference_table, report)
 
 pytestmark = pytest.mark.gpu
 
@@ -17,12 +17,6 @@ TOL = 1e-5          # north_star bound, float32 output vs float64 reference
 F32 = 6e-8          # one float32 rounding of a value <= 1
 DT = 1. / 44100
 WAVES = {'sine': 0, 'square': 1, 'sawtooth': 2, 'triangle': 3}
-REPORT = {}
-
-
-def report(block_type, err):
-    REPORT[block_type] = max(REPORT.get(block_type, 0.), float(err))
-
 
 @pytest.fixture(scope='module')
 def ctx(hip):

@@ -5,7 +5,7 @@ Everything goes through the C-ABI."""
 import numpy as np
 import pytest
 
-from tests.helpers import B, oracle_synth_bank, synth_notes
+from tests.helpers import B, oracle_synth_bank, report, synth_notes
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def test_polyphonic_synthesizer_vs_reference(hip, ctx, golden, key, poly):
     np.testing.assert_array_equal((out / poly).reshape(-1, B), ref)
     # the mix bus (float32), rendered in three calls: routing state carries over
     mix = np.concatenate([bank.render(k) for k in (5, 2, n_blocks - 7)])[:, 0, :]
-    assert np.abs(mix - ref).max() <= 1e-6
+    assert report('PolyphonicSynthesizer', np.abs(mix - ref).max()) <= 1e-6
     state = g[key + '_state']   # currentPhase, currentPitch, amplitude, active, frequency
     np.testing.assert_array_equal(bank.get_state(hip.F_PHASE), state[:, 0])
     np.testing.assert_array_equal(bank.get_state(hip.F_CURRENT_PITCH), state[:, 1])
@@ -75,7 +75,7 @@ def test_monophonic_synthesizer_vs_reference(hip, ctx, golden, policy):
     got = bank.render_voices(len(ref), f64=True)[0].reshape(-1, B)
     np.testing.assert_array_equal(got, ref)
     mix = bank.render(len(ref))[:, 0, :]
-    assert np.abs(mix - ref).max() <= 1e-6
+    assert report('MonophonicSynthesizer', np.abs(mix - ref).max()) <= 1e-6
     assert bank.get_state(hip.F_PHASE)[0] == g['mono_%s_state' % policy][0]
     bank.close()
 
@@ -188,7 +188,7 @@ def test_kick_batch_vs_reference(hip, ctx, golden):
     out = np.concatenate([batch.render(k) for k in (1, 30, 69)], axis=1)
     for i, name in enumerate(('kick_default', 'kick_tom')):
         want = g[name + '_out'].ravel()
-        assert np.abs(out[i] - want).max() <= 1e-11, name
+        assert report('Kick (float64 out)', np.abs(out[i] - want).max()) <= 1e-11, name
     time, phase = batch.state()
     for i, name in enumerate(('kick_default', 'kick_tom')):
         assert abs(time[i] - g[name + '_final'][0]) <= 1e-12
@@ -241,6 +241,7 @@ def test_chirp_batch_vs_reference(hip, ctx, golden):
     t = batch.time_vectors()
     for i, (name, _, _, tol) in enumerate(CHIRPS):
         want = g[name].ravel()
+        report('Chirper %s (float64 out)' % name.split('_')[0], np.abs(out[i] - want).max())
         if tol:
             assert np.abs(out[i] - want).max() <= tol, name
         else:
