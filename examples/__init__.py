@@ -5,25 +5,10 @@ Block / | / + code, `from klang...` replaced by `from klang_amd...`.  Every modu
     python -m examples.hello_world [out.wav]
 
 Message sources of the reference that are control plane and not part of this package
-(Sequencer, MusicalKeyboard) are replaced by `NoteScript`, a host block that sends
-pre-written notes at given buffer numbers."""
-from klang_amd.block import Block
-from klang_amd.wiring import MessageOutput
-
-
-class NoteScript(Block):
-    """Sends `script[k]` (a list of Notes) while buffer k is being executed."""
-
-    def __init__(self, script):
-        super().__init__()
-        self.outputs = [MessageOutput(owner=self)]
-        self.script = {int(k): list(v) for k, v in script.items()}
-        self.buffer = 0
-
-    def update(self):
-        for note in self.script.get(self.buffer, ()):
-            self.output.send(note)
-        self.buffer += 1
+(Sequencer, MusicalKeyboard) are replaced by `klang_amd.notes.NoteScript`, a block that sends
+pre-written notes at given buffer numbers; under backend='hip' an offline bounce hands the
+whole script to the device up front."""
+from klang_amd.notes import NoteScript  # noqa: F401  (the examples import it from here)
 
 
 def bounce(build, default_path, duration, argv=None, **kwargs):

@@ -424,6 +424,35 @@ class GpuVoiceBank(Block):
             self.remaining -= 1
         self.sink.output.set_value(self._ready.pop().astype(np.float64))
 
+    # -- notes known ahead of time (klang_amd.klang.preschedule) ---------------------------
+    def message_targets(self):
+        """{MessageInput: handle} for the inputs whose notes this bank consumes."""
+        if self.synths:
+            return {syn.input: ('synth', i) for i, syn in enumerate(self.synths)}
+        return {c.voice.input: ('voice', i) for i, c in enumerate(self.chains)
+                if c.voice is not None}
+
+    def schedule(self, handle, note, block):
+        """What update() would do with `note` arriving in buffer `block` (counted from the
+        next render), queued now."""
+        F, (kind, i) = native, handle
+        if kind == 'synth':
+            syn = self.synths[i]
+            if self.poly:
+                self.bank.note(i, block, note.pitch, note.velocity, note.frequency)
+                if note.on:
+                    next(syn.freeVoice)
+                    syn.allocated += 1
+                return
+            note = syn.noteScheduler.get_next_note(note)    # MonophonicSynthesizer.process_note
+        voice = self.chains[i].voice
+        if note.on:
+            self.bank.event(i, block, F.EV_NOTE_ON, note.velocity, note.frequency)
+            voice.currentPitch = note.pitch
+        else:
+            self.bank.event(i, block, F.EV_NOTE_OFF)
+            voice.currentPitch = 0
+
     def _feed_external(self):
         """This buffer's samples of the chains' sources -> klmi_bank_set_input."""
         rows = []
@@ -479,9 +508,15 @@ class GpuVoiceBank(Block):
         if self.chains[0].voice is not None:
             value, stage = bank.get_state(F.F_ENV_VALUE), bank.get_state(F.F_ENV_STAGE)
             enabled = bank.get_state(F.F_ENV_ENABLED)
+            amp = bank.get_state(F.F_AMPLITUDE)
             for i, c in enumerate(self.chains):
                 c.envelope.value, c.envelope.stage = float(value[i]), int(stage[i])
                 c.envelope.enabled = bool(enabled[i])
+                c.voice.amplitude = float(amp[i])
+            if self.mod_target != F.MOD_FREQUENCY:
+                for c, f in zip(self.chains, bank.get_state(F.F_FREQUENCY)):
+                    if not c.oscillator.frequency.connected:
+                        c.oscillator.frequency.set_value(float(f))
         if self.poly:   # what the device-side routing decided
             pitch, amp = bank.get_state(F.F_CURRENT_PITCH), bank.get_state(F.F_AMPLITUDE)
             freq = bank.get_state(F.F_FREQUENCY)
@@ -535,13 +570,31 @@ class GpuKick(Block):
                              (native.KICK_INTENSITY, kick.intensity),
                              (native.KICK_PITCH_DECAY, kick.pitchDecay)):
             self.batch.set(field, [float(value)])
-        self.lookahead, self.remaining = 1, None    # set by run_klang; a kick never renders ahead
+        self.lookahead, self.remaining = 1, None    # set by run_klang
+        self._ready = []
+
+    def message_targets(self):
+        return {self.kick.input: ('kick', 0)}
+
+    def schedule(self, handle, note, block):
+        if note.pitch > 0 and note.on:              # synthesizer.py:275-278
+            self.batch.trigger(0, block)
 
     def update(self):
-        for note in self.kick.input.receive():      # synthesizer.py:275-278
-            if note.pitch > 0 and note.on:
-                self.batch.trigger(0, 0)
-        self.kick.output.set_value(self.batch.render(1)[0])
+        notes = list(self.kick.input.receive())
+        if self._ready and notes:
+            raise KlangError('GpuKick: notes arrived while buffers were rendered ahead; use '
+                             'lookahead=1 for patches with live message sources')
+        if not self._ready:
+            for note in notes:
+                self.schedule(None, note, 0)
+            ahead = max(1, int(self.lookahead))
+            if self.remaining is not None:
+                ahead = max(1, min(ahead, int(self.remaining)))
+            self._ready = list(self.batch.render(ahead)[0].reshape(ahead, BUFFER_SIZE))[::-1]
+        if self.remaining is not None:
+            self.remaining -= 1
+        self.kick.output.set_value(self._ready.pop())
 
     def sync_host_blocks(self):
         time, phase = self.batch.state()
@@ -573,6 +626,9 @@ class GpuChirper(Block):
             raise ValueError(str(err)) from None      # scipy's ValueErrors for bad sweeps
         self.lookahead, self.remaining = 1, None
         self._ready = []
+
+    def message_targets(self):
+        return {}
 
     def update(self):
         if not self._ready:

@@ -71,6 +71,41 @@ def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', of
     return list(frames.reshape(-1, BUFFER_SIZE, dac.nChannels))
 
 
+def preschedule(execOrder, banks, n_cycles):
+    """Event pre-computation for an offline bounce: when every message
+    source of the order is a NoteScript whose notes all go to device blocks, queue the whole
+    piece's notes on the device now -- each with the buffer it belongs to, in the order the
+    sources would have sent them -- and drop the sources from the order.  Nothing on the host
+    is left to run between buffers, so the banks may render ahead (or bounce the piece in one
+    pass).  Returns the order to execute."""
+    from klang_amd.notes import NoteScript
+    from klang_amd.wiring import MessageInput
+    sources = [b for b in execOrder if isinstance(b, NoteScript)]
+    if not sources or n_cycles is None:
+        return execOrder
+    targets = {}
+    for bank in banks:
+        for inp, handle in bank.message_targets().items():
+            targets[inp] = (bank, handle)
+    for src in sources:
+        if src.buffer != 0 or any(dst not in targets for dst in src.output.outgoingConnections):
+            return execOrder
+    cap = MessageInput.MAX_MESSAGES     # a queue keeps the newest 50 notes of a buffer
+    for k in range(n_cycles):
+        arrivals = collections.OrderedDict()
+        for src in sources:
+            for note in src.script.get(k, ()):
+                for dst in src.output.outgoingConnections:
+                    arrivals.setdefault(dst, []).append(note)
+        for dst, notes in arrivals.items():
+            bank, handle = targets[dst]
+            for note in notes[-cap:]:
+                bank.schedule(handle, note, k)
+    for src in sources:
+        src.buffer = n_cycles
+    return [b for b in execOrder if b not in sources]
+
+
 def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
     """Run a block network.  kwargs: duration, fadeout, filepath, offline (see
     klang_amd.audio.engine.run_audio_engine).  Returns the list of rendered
@@ -90,11 +125,14 @@ def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
     if backend == 'hip':
         from klang_amd import fusion
         execOrder, banks = fusion.compile_order(execOrder, strict=True)
-        # rendering ahead is safe when nothing on the host can emit a note between buffers
-        only_io = all(isinstance(b, (fusion.GpuVoiceBank, Adc, Dac)) for b in execOrder)
-        ahead = (64 if only_io else 1) if lookahead is None else int(lookahead)
         duration = kwargs.get('duration', INF)
         n_cycles = None if duration == INF else int(duration * SAMPLING_RATE // BUFFER_SIZE)
+        if kwargs.get('offline'):
+            execOrder = preschedule(execOrder, banks, n_cycles)
+        # rendering ahead is safe when nothing on the host can emit a note between buffers
+        device_blocks = (fusion.GpuVoiceBank, fusion.GpuKick, fusion.GpuChirper, Adc, Dac)
+        only_io = all(isinstance(b, device_blocks) for b in execOrder)
+        ahead = (64 if only_io else 1) if lookahead is None else int(lookahead)
         for bank in banks:
             bank.lookahead = ahead
             bank.remaining = n_cycles

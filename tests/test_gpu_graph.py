@@ -347,3 +347,42 @@ def test_monophonic_synthesizer_through_the_api(hip, golden, policy):
     banks[0].sync_host_blocks()
     assert mono.voice.oscillator.currentPhase == g['mono_%s_state' % policy][0]
     banks[0].close()
+
+
+# ---- notes known ahead of time (event pre-computation) ---------------------
+def test_note_scripts_are_prescheduled_for_an_offline_bounce(hip, golden, monkeypatch):
+    """NoteScript | PolyphonicSynthesizer | Dac, offline: all notes reach the device before the
+    first buffer and the piece is ONE device bounce; same samples as the fixture of the real
+    reference (which got the notes buffer by buffer)."""
+    from klang_amd.audio import PolyphonicSynthesizer
+    from klang_amd.notes import NoteScript
+    g = golden('synthesizer')
+    script = {}
+    for blk, pitch, velocity, frequency in g['poly24_notes']:
+        script.setdefault(int(blk), []).append(Note(int(pitch), velocity, frequency))
+    calls = []
+    real = fusion.GpuVoiceBank.bounce
+    monkeypatch.setattr(fusion.GpuVoiceBank, 'bounce',
+                        lambda self, *a, **kw: (calls.append(1), real(self, *a, **kw))[1])
+    source = NoteScript(script)
+    poly = PolyphonicSynthesizer(_synth_template(g))
+    n = len(g['poly24_out'])
+    frames = run_klang(source | poly | Dac(), offline=True, duration=(n + .5) * B / 44100.)
+    assert calls == [1] and source.buffer == n
+    got = np.concatenate(frames)[:, 0].reshape(n, B)
+    assert np.abs(got - g['poly24_out']).max() <= 1e-6
+    assert [v.currentPitch for v in poly.voices] == list(g['poly24_state'][:, 1].astype(int))
+    assert poly.allocated == int((g['poly24_notes'][:, 2] > 0).sum())
+
+
+def test_prescheduled_mono_synths_and_kick_render_ahead(hip):
+    """Three sources of different kinds into one Mixer (the drum machine): prescheduled, the
+    banks render 64 buffers ahead; equal to the host evaluation that gets the notes live."""
+    import examples.drum_machine as dm
+    dur = 150 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(dm.build(), offline=True, duration=dur))
+    want = np.concatenate(run_klang(dm.build(), offline=True, duration=dur, backend='host'))
+    assert np.abs(got - want).max() <= 1e-6 and np.abs(want).max() > .1
+    # live (buffer by buffer) on the device gives the same samples as prescheduled
+    live = np.concatenate(run_klang(dm.build(), offline=True, duration=dur, lookahead=1))
+    assert np.abs(live - got).max() <= 1e-7
