@@ -49,7 +49,7 @@ def cpu_baseline(n_voices, log):
     table, grid = library_table(native)
     threads = max(1, min(oracle.max_threads(), int(os.environ.get('OMP_NUM_THREADS', '16')), 16))
     out = {}
-    for label, nthreads, blocks in (('single', 1, 4), ('all', threads, 32)):
+    for label, nthreads, blocks in (('single', 1, 8), ('all', threads, 64)):   # ~20 core-seconds
         patch = patches.polyphonic_saw_patch(n_voices=n_voices, n_blocks=blocks, off_base=2,
                                              off_span=max(1, blocks // 2))
         bank = oracle_bank_from_patch(oracle, patch, table, grid)
