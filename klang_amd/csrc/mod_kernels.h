@@ -219,10 +219,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         delay_len = (int)par[0];
         delay_fb = par[n], delay_dw = par[2 * n];
     }
-    double fx_p0[8];   // first parameter of every stage (a second one is fetched where used)
+    unsigned long long fx_kinds = 0;   // stage kinds, one byte each (scalar)
 #pragma unroll
     for (int s = 0; s < 8; ++s)
-        fx_p0[s] = s < n_fx ? bk.fx_par[(size_t)(s * kFxSlots) * n + v] : 0.;
+        fx_kinds |= (unsigned long long)(s < n_fx ? bk.fx_kind[s] : 0) << (8 * s);
 
     double gl = 0., gr = 0.;
     if (MIX) {
@@ -442,10 +442,13 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             x[j] = bq.step(x[j]);
                     }
                 } else {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) {   // wave-uniform program, parameters in registers
-                        const double p0 = fx_p0[s];
-                        switch (s < n_fx ? (int)bk.fx_kind[s] : (int)FX_NONE) {
+                    // wave-uniform program: a run-time loop (one copy of the stage code); the
+                    // stage kinds were unpacked into scalar registers, the first parameter of
+                    // a stage comes from the (cache-resident) parameter rows
+#pragma nounroll
+                    for (int s = 0; s < n_fx; ++s) {
+                        const double p0 = bk.fx_par[(size_t)(s * kFxSlots) * n + v];
+                        switch ((int)((fx_kinds >> (8 * s)) & 0xFFu)) {
                         case FX_FILTER:
 #pragma unroll
                             for (int j = 0; j < G; ++j)
