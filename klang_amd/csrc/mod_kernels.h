@@ -69,6 +69,29 @@ __device__ __forceinline__ void wave_block(int sel, int lane_wave, const double 
     }
 }
 
+// G remainders mod TAU.  FAST (wave-uniform: every argument is finite, >= 0 and < 1e9):
+// speculate r = fma(-floor(a / TAU), TAU, a) -- exact unless the quotient estimate is off by
+// one -- with ONE range check over the group's high words, as voice_kernel does; a hit in any
+// lane redoes the group with the repairing form.  Otherwise the exact per-element remainder.
+template <bool BD, int G>
+__device__ __forceinline__ void mod_tau_group(bool fast, const double (&a)[G], double (&p)[G])
+{
+    if (BD && fast) {
+        uint32_t hi_max = 0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const double k = floor(a[j] * kInvTau);
+            p[j] = __builtin_fma(-k, kTau, a[j]);
+            hi_max = max(hi_max, (uint32_t)__double2hiint(p[j]));
+        }
+        if (__builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) == 0)
+            return;
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        p[j] = np_mod_tau_sel<BD>(a[j]);
+}
+
 // two float64 at 8-byte alignment (one 16-byte access)
 struct __attribute__((packed, aligned(8))) Double2U {
     double a, b;
@@ -331,6 +354,11 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             fabs(kTau * trem_rate) * t_end + fabs(trem_start) < 1e9 &&
             fabs(kTau * ring_rate) * t_end + fabs(ring_lfo_start) < 1e9 &&
             (kTau * kDt) * kBlock * (fabs(ring_freq) + fabs(ring_amount)) + fabs(ring_start) < 1e9);
+        // ... and which of the closed-form phases are non-negative throughout (fast remainder)
+        const bool pos_osc = bounded_block && __all(omega >= 0. && start >= 0.);
+        const bool pos_mod = bounded_block && __all(mod_omega >= 0. && mod_start >= 0.);
+        const bool pos_trem = bounded_block && __all(trem_rate >= 0. && trem_start >= 0.);
+        const bool pos_ring = bounded_block && __all(ring_rate >= 0. && ring_lfo_start >= 0.);
 
         // Eight oscillator samples (with the modulator's): per sample the reference's
         // operations in the reference's order, but staged over the group so that every
@@ -338,11 +366,12 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         auto osc_group = [&](auto bounded, const TimeG &tt, bool block_start, int sample0,
                              double (&x)[G]) {
             constexpr bool BD = decltype(bounded)::value;
-            double m[G], p[G];
+            double m[G], p[G], arg[G];
             if (target != MT_NONE) {   // Oscillator.sample / Lfo.sample with shape 256
 #pragma unroll
                 for (int j = 0; j < G; ++j)
-                    p[j] = np_mod_tau_sel<BD>(mod_omega * tt.t[j] + mod_start);
+                    arg[j] = mod_omega * tt.t[j] + mod_start;
+                mod_tau_group<BD, G>(pos_mod, arg, p);
                 wave_block<true, BD, G>(uniform_mod_wave, mod_wave, p, kPi, m);
                 if (target != MT_FM) {
 #pragma unroll
@@ -373,7 +402,8 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             } else {
 #pragma unroll
                 for (int j = 0; j < G; ++j)
-                    p[j] = np_mod_tau_sel<BD>(omega * tt.t[j] + start);
+                    arg[j] = omega * tt.t[j] + start;
+                mod_tau_group<BD, G>(pos_osc, arg, p);
             }
             if (target == MT_FM) {          // oscillators.py:220: any phase
 #pragma unroll
@@ -476,17 +506,25 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             for (int j = 0; j < G; ++j)
                                 x[j] = 2. * (x[j] * x[j]) - 1.;
                             break;
-                        case FX_TREMOLO:    // effects.py:117-133
+                        case FX_TREMOLO: {  // effects.py:117-133
+                            double pa[G], tp[G];
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                pa[j] = kTau * trem_rate * tt.t[j] + trem_start;
+                            if (bounded_block)
+                                mod_tau_group<true, G>(pos_trem, pa, tp);
+                            else
+                                mod_tau_group<false, G>(false, pa, tp);
 #pragma unroll
                             for (int j = 0; j < G; ++j) {
-                                const double pa = kTau * trem_rate * tt.t[j] + trem_start;
-                                const double p = bounded_block ? np_mod_tau_bounded(pa) : np_mod_tau(pa);
+                                const double p = tp[j];
                                 const double pwm = (p < kTau * trem_duty) ? 1. : -1.;
                                 const double y = trem_z + trem_b0 * pwm;   // lfilter([b0], [1, a1])
                                 trem_z = 0. * pwm - trem_a1 * y;
                                 x[j] = ((1. - trem_depth) + trem_depth * (.5 + .5 * y)) * x[j];
                             }
                             break;
+                        }
                         case FX_DELAY: {    // effects.py:166-174 (the blend reads the window after
                                             // the write: wet = new + feedback * delayed)
                             // The voice's own line is contiguous (positions differ from voice to
@@ -547,9 +585,11 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             double f[G], ph[G], am[G];
 #pragma unroll
                             for (int j = 0; j < G; ++j)     // the Lfo: Oscillator.sample, scalar rate
-                                ph[j] = bounded_block
-                                            ? np_mod_tau_bounded(kTau * ring_rate * tt.t[j] + ring_lfo_start)
-                                            : np_mod_tau(kTau * ring_rate * tt.t[j] + ring_lfo_start);
+                                am[j] = kTau * ring_rate * tt.t[j] + ring_lfo_start;
+                            if (bounded_block)
+                                mod_tau_group<true, G>(pos_ring, am, ph);
+                            else
+                                mod_tau_group<false, G>(false, am, ph);
                             wave_block<true, false, G>(-1, ring_wave, ph, kPi, f);
 #pragma unroll
                             for (int j = 0; j < G; ++j) {   // modulator: array branch of sample_phase
