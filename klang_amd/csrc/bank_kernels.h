@@ -102,11 +102,26 @@ template <> struct TileTraits<OUT_VOICES_F32> { using T = float; static constexp
 template <> struct TileTraits<OUT_VOICES_F64> { using T = double; static constexpr int chunk = 32, stride = 65, planes = 1; };
 template <> struct TileTraits<OUT_BUS_F64> { using T = double; static constexpr int chunk = 64, stride = 1, planes = 0; };
 
-// high 32 bits of TAU = 0x401921FB54442D18
-constexpr uint32_t kTauHighWord = 0x401921FBu;
-
 constexpr int kWavesPerGroup = 4;
 constexpr int kGroup = 64 * kWavesPerGroup;
+
+// LDS bytes of a workgroup's mix-down / transpose tiles
+template <int MODE> __host__ __device__ constexpr size_t tile_bytes()
+{
+    using TT = TileTraits<MODE>;
+    return sizeof(typename TT::T) * (size_t)kWavesPerGroup * (TT::planes ? TT::planes : 1) * TT::chunk *
+           TT::stride;
+}
+// general kernel with effect stages: samples per wave strip (float64 [kFxStrip][64] per wave)
+constexpr int kFxStrip = 32;
+template <int MODE> __host__ __device__ constexpr size_t fx_strip_bytes()
+{
+    using TT = TileTraits<MODE>;
+    return sizeof(double) * (size_t)kWavesPerGroup * (kFxStrip < TT::chunk ? kFxStrip : TT::chunk) * 64;
+}
+
+// high 32 bits of TAU = 0x401921FB54442D18
+constexpr uint32_t kTauHighWord = 0x401921FBu;
 
 // Sum of one tile row (64 voices) read as 16 x ds_read_b128, pairwise order.
 __device__ __forceinline__ float row_sum64(const float *row)

@@ -19,11 +19,4 @@ hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, cons
                              int first, int count, int block_base, uint32_t clock_base,
                              int n_blocks, int span_total, float *partial, void *out);
 
-template <int MODE> inline size_t tile_bytes()
-{
-    using TT = TileTraits<MODE>;
-    const int planes = TT::planes ? TT::planes : 1;
-    return sizeof(typename TT::T) * (size_t)kWavesPerGroup * planes * TT::chunk * TT::stride;
-}
-
 }  // namespace klmi

@@ -137,6 +137,9 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     T *tile = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (PLANES ? PLANES : 1) * CH * TT::stride;
+    // HAS_FX: the wave's float64 strip of SUB samples x 64 lanes behind the tiles
+    constexpr int SUB = kFxStrip < CH ? kFxStrip : CH;
+    double *strip = reinterpret_cast<double *>(smem_raw + tile_bytes<MODE>()) + (size_t)wave * SUB * 64;
 
     const int local = blockIdx.x * kGroup + threadIdx.x;
     const bool live = local < count;
@@ -435,9 +438,9 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             // registers, and the G delayed samples of a Delay stage fetched together (the line
             // is at least one buffer long, so they never depend on this block's writes).
             // Arithmetic per sample is exactly the per-sample reference order.
-            for (int i8 = 0; i8 < CH; i8 += G) {
+            // oscillator, modulator and envelope for samples [i8, i8 + G) of the chunk
+            auto voice_group = [&](int i8, double (&x)[G]) {
                 const TimeG tt = load_times<G>(times, i8);
-                double x[G];
                 // -- oscillator and its modulator ---------------------------------------
                 if (bounded_block)
                     osc_group(std::true_type{}, tt, c == 0 && i8 == 0, s0 + i8, x);
@@ -464,156 +467,252 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                     for (int j = 0; j < G; ++j)
                         x[j] = amp * x[j] * e[j];
                 }
-                // -- stages -----------------------------------------------------------------
-                if (!HAS_FX) {
+            };
+            if constexpr (!HAS_FX) {
+                // G samples per group, everything in registers
+                for (int i8 = 0; i8 < CH; i8 += G) {
+                    double x[G];
+                    voice_group(i8, x);
                     if (has_filter) {
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             x[j] = bq.step(x[j]);
                     }
-                } else {
-                    // wave-uniform program: a run-time loop (one copy of the stage code); the
-                    // stage kinds were unpacked into scalar registers, the first parameter of
-                    // a stage comes from the (cache-resident) parameter rows
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        emit_sample<MODE>(tile, i8 + j, lane, x[j], gl, gr, live, out, s0, count, local);
+                }
+            } else {
+                // Stage-major over sub-chunks of SUB samples that live in the wave's LDS strip
+                // (float64 [SUB][64 lanes], lane-contiguous: conflict-free 8-byte accesses):
+                // the voice fills the strip, every stage of the wave-uniform program runs its own
+                // tight loop over it, the last pass hands the samples to the mix-down tile.  A
+                // stage's state is live in its own loop only, so the stage program no longer
+                // fights over the register file (the group-major form spent most of its
+                // instructions on register copies); the price is two LDS accesses per sample
+                // and stage.  The stage kinds were unpacked into scalar registers; a stage's
+                // first parameter comes from the (cache-resident) parameter rows.
+                auto load_x = [&](int i, double (&x)[G]) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        x[j] = strip[(i + j) * 64 + lane];
+                };
+                auto store_x = [&](int i, const double (&x)[G]) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        strip[(i + j) * 64 + lane] = x[j];
+                };
+                for (int half = 0; half < CH; half += SUB) {
+                    for (int i8 = half; i8 < half + SUB; i8 += G) {
+                        double x[G];
+                        voice_group(i8, x);
+                        store_x(i8 - half, x);
+                    }
 #pragma nounroll
                     for (int s = 0; s < n_fx; ++s) {
                         const double p0 = bk.fx_par[(size_t)(s * kFxSlots) * n + v];
                         switch ((int)((fx_kinds >> (8 * s)) & 0xFFu)) {
-                        case FX_FILTER:
+                        case FX_FILTER: {
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
 #pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                x[j] = bq.step(x[j]);
-                            break;
-                        case FX_GAIN:       // effects.py:67-70
-#pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                x[j] = p0 * x[j];
-                            break;
-                        case FX_TRANSFORM: {  // effects.py:558-561
-                            const double p1 = bk.fx_par[(size_t)(s * kFxSlots + 1) * n + v];
-#pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                x[j] = p0 * x[j] + p1;
+                                for (int j = 0; j < G; ++j)
+                                    x[j] = bq.step(x[j]);
+                                store_x(i8 - half, x);
+                            }
                             break;
                         }
-                        case FX_TANH:       // effects.py:480-483
+                        case FX_GAIN: {       // effects.py:67-70
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
 #pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                x[j] = tanh(p0 * x[j]);
+                                for (int j = 0; j < G; ++j)
+                                    x[j] = p0 * x[j];
+                                store_x(i8 - half, x);
+                            }
                             break;
-                        case FX_OCTAVE:     // effects.py:460-462
+                        }
+                        case FX_TRANSFORM: {  // effects.py:558-561
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+                                const double p1 = bk.fx_par[(size_t)(s * kFxSlots + 1) * n + v];
 #pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                x[j] = 2. * (x[j] * x[j]) - 1.;
+                                for (int j = 0; j < G; ++j)
+                                    x[j] = p0 * x[j] + p1;
+                        
+                                store_x(i8 - half, x);
+                            }
                             break;
+                        }
+                        case FX_TANH: {       // effects.py:480-483
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+#pragma unroll
+                                for (int j = 0; j < G; ++j)
+                                    x[j] = tanh(p0 * x[j]);
+                                store_x(i8 - half, x);
+                            }
+                            break;
+                        }
+                        case FX_OCTAVE: {     // effects.py:460-462
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+#pragma unroll
+                                for (int j = 0; j < G; ++j)
+                                    x[j] = 2. * (x[j] * x[j]) - 1.;
+                                store_x(i8 - half, x);
+                            }
+                            break;
+                        }
                         case FX_TREMOLO: {  // effects.py:117-133
-                            double pa[G], tp[G];
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+                                const TimeG tt = load_times<G>(times, i8);
+                                double pa[G], tp[G];
 #pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                pa[j] = kTau * trem_rate * tt.t[j] + trem_start;
-                            if (bounded_block)
-                                mod_tau_group<true, G>(pos_trem, pa, tp);
-                            else
-                                mod_tau_group<false, G>(false, pa, tp);
+                                for (int j = 0; j < G; ++j)
+                                    pa[j] = kTau * trem_rate * tt.t[j] + trem_start;
+                                if (bounded_block)
+                                    mod_tau_group<true, G>(pos_trem, pa, tp);
+                                else
+                                    mod_tau_group<false, G>(false, pa, tp);
 #pragma unroll
-                            for (int j = 0; j < G; ++j) {
-                                const double p = tp[j];
-                                const double pwm = (p < kTau * trem_duty) ? 1. : -1.;
-                                const double y = trem_z + trem_b0 * pwm;   // lfilter([b0], [1, a1])
-                                trem_z = 0. * pwm - trem_a1 * y;
-                                x[j] = ((1. - trem_depth) + trem_depth * (.5 + .5 * y)) * x[j];
+                                for (int j = 0; j < G; ++j) {
+                                    const double p = tp[j];
+                                    const double pwm = (p < kTau * trem_duty) ? 1. : -1.;
+                                    const double y = trem_z + trem_b0 * pwm;   // lfilter([b0], [1, a1])
+                                    trem_z = 0. * pwm - trem_a1 * y;
+                                    x[j] = ((1. - trem_depth) + trem_depth * (.5 + .5 * y)) * x[j];
+                                }
+                        
+                                store_x(i8 - half, x);
                             }
                             break;
                         }
                         case FX_DELAY: {    // effects.py:166-174 (the blend reads the window after
-                                            // the write: wet = new + feedback * delayed)
-                            // The voice's own line is contiguous (positions differ from voice to
-                            // voice, so nothing coalesces ACROSS lanes: a lane's 8 slots = 64 B of
-                            // one cache line).  Slots [len, len+8) mirror slots [0, 8), so the 8
-                            // reads never wrap; length >= a buffer, so they never see this
-                            // block's writes.
-                            int idx0 = delay_pos + c * CH + i8;
-                            idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
-                            double *line = delay_line + idx0;
-                            double w[G];
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+                                                // the write: wet = new + feedback * delayed)
+                                // The voice's own line is contiguous (positions differ from voice to
+                                // voice, so nothing coalesces ACROSS lanes: a lane's 8 slots = 64 B of
+                                // one cache line).  Slots [len, len+8) mirror slots [0, 8), so the 8
+                                // reads never wrap; length >= a buffer, so they never see this
+                                // block's writes.
+                                int idx0 = delay_pos + c * CH + i8;
+                                idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
+                                double *line = delay_line + idx0;
+                                double w[G];
 #pragma unroll
-                            for (int j = 0; j < G; j += 2) {
-                                const Double2U old = reinterpret_cast<const Double2U *>(line)[j >> 1];
-                                w[j] = x[j] + delay_fb * old.a;
-                                w[j + 1] = x[j + 1] + delay_fb * old.b;
-                            }
-                            if (live) {
+                                for (int j = 0; j < G; j += 2) {
+                                    const Double2U old = reinterpret_cast<const Double2U *>(line)[j >> 1];
+                                    w[j] = x[j] + delay_fb * old.a;
+                                    w[j + 1] = x[j + 1] + delay_fb * old.b;
+                                }
+                                if (live) {
 #pragma unroll
-                                for (int j = 0; j < G; j += 2)
-                                    reinterpret_cast<Double2U *>(line)[j >> 1] = Double2U{w[j], w[j + 1]};
-                                // keep slots and mirror in step where the 8 touch either end
-                                if (idx0 < 8 || idx0 + G > delay_len) {
+                                    for (int j = 0; j < G; j += 2)
+                                        reinterpret_cast<Double2U *>(line)[j >> 1] = Double2U{w[j], w[j + 1]};
+                                    // keep slots and mirror in step where the 8 touch either end
+                                    if (idx0 < 8 || idx0 + G > delay_len) {
 #pragma unroll
-                                    for (int j = 0; j < G; ++j) {
-                                        const int idx = idx0 + j;
-                                        if (idx >= delay_len)
-                                            delay_line[idx - delay_len] = w[j];
-                                        else if (idx < 8)
-                                            delay_line[idx + delay_len] = w[j];
+                                        for (int j = 0; j < G; ++j) {
+                                            const int idx = idx0 + j;
+                                            if (idx >= delay_len)
+                                                delay_line[idx - delay_len] = w[j];
+                                            else if (idx < 8)
+                                                delay_line[idx + delay_len] = w[j];
+                                        }
                                     }
                                 }
-                            }
 #pragma unroll
-                            for (int j = 0; j < G; ++j)
-                                x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
+                                for (int j = 0; j < G; ++j)
+                                    x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
+                        
+                                store_x(i8 - half, x);
+                            }
                             break;
                         }
                         case FX_SUBSAMPLE: {  // effects.py:400-415: np.repeat(x[::skip], skip)
-                            const int mask = (int)p0 - 1;
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+                                const int mask = (int)p0 - 1;
 #pragma unroll
-                            for (int j = 0; j < G; ++j) {
-                                held = ((c * CH + i8 + j) & mask) == 0 ? x[j] : held;
-                                x[j] = held;
+                                for (int j = 0; j < G; ++j) {
+                                    held = ((c * CH + i8 + j) & mask) == 0 ? x[j] : held;
+                                    x[j] = held;
+                                }
+                        
+                                store_x(i8 - half, x);
                             }
                             break;
                         }
                         case FX_BITCRUSH: {   // effects.py:434-447, wavfile.py:14-30
-                            const int bits = (int)p0;
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+                                const int bits = (int)p0;
 #pragma unroll
-                            for (int j = 0; j < G; ++j) {
-                                const int q = (int)(short)(int)(32767. * x[j]);  // astype(int16)
-                                x[j] = (double)(int)(short)((q >> bits) << bits) * (1. / 32768.);
+                                for (int j = 0; j < G; ++j) {
+                                    const int q = (int)(short)(int)(32767. * x[j]);  // astype(int16)
+                                    x[j] = (double)(int)(short)((q >> bits) << bits) * (1. / 32768.);
+                                }
+                        
+                                store_x(i8 - half, x);
                             }
                             break;
                         }
                         case FX_RINGMOD: {    // effects.py:650-662
-                            double f[G], ph[G], am[G];
+                            for (int i8 = half; i8 < half + SUB; i8 += G) {
+                                double x[G];
+                                load_x(i8 - half, x);
+                                const TimeG tt = load_times<G>(times, i8);
+                                double f[G], ph[G], am[G];
 #pragma unroll
-                            for (int j = 0; j < G; ++j)     // the Lfo: Oscillator.sample, scalar rate
-                                am[j] = kTau * ring_rate * tt.t[j] + ring_lfo_start;
-                            if (bounded_block)
-                                mod_tau_group<true, G>(pos_ring, am, ph);
-                            else
-                                mod_tau_group<false, G>(false, am, ph);
-                            wave_block<true, false, G>(-1, ring_wave, ph, kPi, f);
+                                for (int j = 0; j < G; ++j)     // the Lfo: Oscillator.sample, scalar rate
+                                    am[j] = kTau * ring_rate * tt.t[j] + ring_lfo_start;
+                                if (bounded_block)
+                                    mod_tau_group<true, G>(pos_ring, am, ph);
+                                else
+                                    mod_tau_group<false, G>(false, am, ph);
+                                wave_block<true, false, G>(-1, ring_wave, ph, kPi, f);
 #pragma unroll
-                            for (int j = 0; j < G; ++j) {   // modulator: array branch of sample_phase
-                                const double fj = ring_freq + ring_amount * f[j];
-                                const bool first_sample = c == 0 && i8 == 0 && j == 0;
-                                const double arg = first_sample ? ring_start
-                                                                : (kTau * kDt) * ring_running + ring_start;
-                                ph[j] = bounded_block ? np_mod_tau_bounded(arg) : np_mod_tau(arg);
-                                ring_running = first_sample ? fj : ring_running + fj;
+                                for (int j = 0; j < G; ++j) {   // modulator: array branch of sample_phase
+                                    const double fj = ring_freq + ring_amount * f[j];
+                                    const bool first_sample = c == 0 && i8 == 0 && j == 0;
+                                    const double arg = first_sample ? ring_start
+                                                                    : (kTau * kDt) * ring_running + ring_start;
+                                    ph[j] = bounded_block ? np_mod_tau_bounded(arg) : np_mod_tau(arg);
+                                    ring_running = first_sample ? fj : ring_running + fj;
+                                }
+                                wave_block<true, false, G>(W_SINE, W_SINE, ph, kPi, am);
+#pragma unroll
+                                for (int j = 0; j < G; ++j)     // math.py:68-75 blend(x, am * x, dryWet)
+                                    x[j] = (1. - ring_dw) * x[j] + ring_dw * (am[j] * x[j]);
+                        
+                                store_x(i8 - half, x);
                             }
-                            wave_block<true, false, G>(W_SINE, W_SINE, ph, kPi, am);
-#pragma unroll
-                            for (int j = 0; j < G; ++j)     // math.py:68-75 blend(x, am * x, dryWet)
-                                x[j] = (1. - ring_dw) * x[j] + ring_dw * (am[j] * x[j]);
                             break;
                         }
                         default:
                             break;
                         }
                     }
-                }
+                    for (int i8 = half; i8 < half + SUB; i8 += G) {
+                        double x[G];
+                        load_x(i8 - half, x);
 #pragma unroll
-                for (int j = 0; j < G; ++j)
-                    emit_sample<MODE>(tile, i8 + j, lane, x[j], gl, gr, live, out, s0, count, local);
+                        for (int j = 0; j < G; ++j)
+                            emit_sample<MODE>(tile, i8 + j, lane, x[j], gl, gr, live, out, s0, count, local);
+                    }
+                }
             }
             flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
         }

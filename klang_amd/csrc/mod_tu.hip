@@ -17,7 +17,7 @@ static hipError_t launch(bool env, bool filt, hipStream_t st, const BankView &vi
     static bool configured[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    const size_t smem = tile_bytes<MODE>();
+    const size_t smem = tile_bytes<MODE>() + (HAS_FX ? fx_strip_bytes<MODE>() : 0);
     auto kernel = voice_mod_kernel<MODE, HAS_FX>;
     if (dev < 16 && !configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
