@@ -11,10 +11,11 @@
 // Same mapping and data layout as voice_kernel (one lane = one voice, state in registers
 // for the whole launch, the wave's LDS tile for the mix-down); one lane's time axis is
 // serial anyway, so the running frequency sum needs no cross-lane scan.  Samples are
-// handled in groups of eight (one scalar load of the time points, stage parameters in
-// registers, a Delay stage's eight reads in flight together); the arithmetic per sample
-// is the reference's.  Envelope and filter are run-time options so that only the output
-// mode is a template parameter.
+// handled in groups of eight (one scalar load of the time points, speculative remainders
+// and envelope with one check per group); the arithmetic per sample is the reference's.
+// Chains with effect stages run stage-major over a wave-private LDS strip (see HAS_FX).
+// Envelope and filter are run-time options so that only the output mode and HAS_FX are
+// template parameters.
 #pragma once
 #include "bank_kernels.h"
 #include <type_traits>
@@ -596,10 +597,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             break;
                         }
                         case FX_DELAY: {    // effects.py:166-174 (the blend reads the window after
+                                            // the write: wet = new + feedback * delayed)
                             for (int i8 = half; i8 < half + SUB; i8 += G) {
                                 double x[G];
                                 load_x(i8 - half, x);
-                                                // the write: wet = new + feedback * delayed)
                                 // The voice's own line is contiguous (positions differ from voice to
                                 // voice, so nothing coalesces ACROSS lanes: a lane's 8 slots = 64 B of
                                 // one cache line).  Slots [len, len+8) mirror slots [0, 8), so the 8
