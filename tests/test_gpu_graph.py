@@ -239,11 +239,33 @@ def _effect_patches():
                       | Bitcrusher(4 + k) | Subsampler(2 ** (k + 1)))
         return mixer | Dac()
 
+    def stereo_stages():      # effect stages under a StereoMixer (stereo tiles, 32-sample chunks)
+        from klang_amd.audio import Bitcrusher, RingModulator
+        mixer = StereoMixer()
+        for k in range(5):
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+            voice.input.push(Note(0, .7, frequency=82.4 * (k + 1)))
+            mixer += (voice | Filter(frequency=600. + 400 * k) | Tremolo(rate=2. + k, depth=.6)
+                      | Delay(time=.011 + .003 * k, feedback=.5) | RingModulator(200., 1., 10., dryWet=.2)
+                      | Bitcrusher(3) | Gain(.9))
+            mixer.pannings[-1] = -1. + .5 * k
+        return mixer | Dac(nChannels=2)
+
+    def stages_into_reverb():  # stages in front of a Reverb (time-major float64 bus output)
+        mixer = Mixer()
+        for k in range(3):
+            voice = Voice(Oscillator(wave_func=sine), ADSR(.01, .05, .6, .04))
+            voice.input.push(Note(0, .7, frequency=110. * (k + 2)))
+            mixer += (voice | TanhDistortion(1.5 + k) | Delay(time=.02, feedback=.3)
+                      | Reverb(decay=1., dryWet=.5))
+        return mixer | Dac()
+
     return dict(arpeggiator_like=arpeggiator_like, tremolo_chain=tremolo_chain, shaping=shaping,
-                lofi=lofi)
+                lofi=lofi, stereo_stages=stereo_stages, stages_into_reverb=stages_into_reverb)
 
 
-@pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping', 'lofi'])
+@pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping', 'lofi',
+                                  'stereo_stages', 'stages_into_reverb'])
 def test_effect_patches_match_the_host_evaluation(hip, name):
     build = _effect_patches()[name]
     order, banks = fusion.compile_order(determine_execution_order([build()]))
