@@ -18,6 +18,7 @@ from klang_amd.audio.signals import Oscillator, PwmOscillator, square
 from klang_amd.block import Block
 from klang_amd.composite import Composite
 from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
+from klang_amd.ring_buffer import RingBuffer
 from klang_amd.constants import MONO
 from klang_amd.tempo import compute_duration
 from klang_amd.wiring import Input, Relay
@@ -135,39 +136,7 @@ class Tremolo(Composite):
         self.output.set_value(env * self.input.value)
 
 
-class DelayLine:
-    """Circular sample store with klang.ring_buffer.RingBuffer's contract
-    (ring_buffer.py:10-113): `length` live samples inside a store that is
-    over-allocated by one buffer, whose first `bufferSize` samples are mirrored
-    behind the end so that a window starting at any position is contiguous.
-    ``peek()`` returns a VIEW (no copy), exactly like the reference."""
-
-    def __init__(self, length, capacity=None, bufferSize=BUFFER_SIZE):
-        self.length = int(length)
-        self.capacity = self.length if capacity is None else int(capacity)
-        self.bufferSize = bufferSize
-        self.data = np.zeros(self.capacity + bufferSize)
-        self.pos = 0
-
-    def peek(self, nValues=None):
-        count = self.bufferSize if nValues is None else nValues
-        return self.data[self.pos:self.pos + count]
-
-    def extend(self, values):
-        count = len(values)
-        if count > self.bufferSize:
-            raise ValueError('To many samples!')
-        first, last = self.pos, self.pos + count
-        self.data[first:last] = values
-        if first < self.bufferSize:                      # keep the mirror behind the end
-            lo = first + self.length
-            hi = min(self.length + self.bufferSize, last + self.length)
-            self.data[lo:hi] = values[:hi - lo]
-        if last > self.length:                           # wrapped: the head gets the rest
-            lo = max(0, first - self.length)
-            hi = last - self.length
-            self.data[lo:hi] = values[-(hi - lo):]
-        self.pos = (self.pos + count) % self.length
+DelayLine = RingBuffer   # the Delay's line is the reference's RingBuffer (effects.py:158)
 
 
 class Delay(Block):

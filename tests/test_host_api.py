@@ -317,3 +317,74 @@ def test_fuser_recognises_effect_stages():
     trem = Oscillator() | Tremolo(rate=4.)
     groups, errors = fusion.find_fusable(determine_execution_order([trem]))
     assert not errors and groups[0][1][0].program == (native.FX_TREMOLO,)
+
+
+# ---- RingBuffer (klang/ring_buffer.py; the reference's tests/test_ring_buffer.py restated) ----
+def test_ring_buffer_known_answers():
+    from klang_amd.ring_buffer import RingBuffer
+    eq = np.testing.assert_array_equal
+    ring = RingBuffer(7, bufferSize=4)
+    eq(ring.data, 11 * [0.])
+    assert ring.pos == 0
+    for i in range(5):
+        ring.append(10 + i)
+    assert ring.pos == 5
+    eq(ring.data, [10, 11, 12, 13, 14, 0, 0, 10, 11, 12, 13])
+    ring = RingBuffer(7, bufferSize=4)
+    ring.extend([1, 2, 3, 4])
+    assert ring.pos == 4
+    eq(ring.data, [1, 2, 3, 4, 0, 0, 0, 1, 2, 3, 4])
+    ring.extend([11, 12, 13, 14])
+    assert ring.pos == 1
+    eq(ring.data, [14, 2, 3, 4, 11, 12, 13, 14, 2, 3, 4])
+    ring.extend([111, 112, 113, 114])
+    assert ring.pos == 5
+    eq(ring.data, [14, 111, 112, 113, 114, 12, 13, 14, 111, 112, 113])
+    ring = RingBuffer(7, bufferSize=4)       # ragged writes
+    for chunk in ([0.], [1., 2.], [3., 4., 5.], [6., 7.]):
+        ring.extend(chunk)
+    eq(ring.data, [7, 1, 2, 3, 4, 5, 6, 7, 1, 2, 3])
+    with pytest.raises(ValueError):
+        ring.extend([1, 2, 3, 4, 5])
+    with pytest.raises(ValueError):
+        ring.length = 8
+    ring = RingBuffer(7, bufferSize=4)       # peeking
+    eq(ring.peek(), [0, 0, 0, 0])
+    ring.extend([1, 2, 3, 4])
+    eq(ring.peek(), [0, 0, 0, 1])
+    ring.extend([5, 6, 7, 8])
+    eq(ring.peek(), [2, 3, 4, 5])
+    assert ring.peek().base is ring.data     # a view, not a copy
+    ring = RingBuffer(7, bufferSize=4)
+    eq(ring.peek_extend([1, 2, 3, 4]), [0, 0, 0, 0])
+    eq(ring.peek_extend([5, 6, 7, 8]), [0, 0, 0, 1])
+    eq(ring.peek_extend([9, 10, 11, 12]), [2, 3, 4, 5])
+    assert repr(RingBuffer(5, capacity=9)) == 'RingBuffer(length=5, capacity=9)'
+
+
+def test_ring_buffer_as_delay_line():
+    from klang_amd.ring_buffer import RingBuffer
+    eq = np.testing.assert_array_equal
+    ring = RingBuffer(7, bufferSize=4)       # a delay of 7 samples
+    x = np.zeros(20)
+    x[0] = 1.
+    y = np.concatenate([ring.peek_extend(row) for row in x.reshape(-1, 4)])
+    want = np.zeros(20)
+    want[7] = 1.
+    eq(y, want)
+    ring = RingBuffer(7, bufferSize=4, nChannels=2)
+    audio = np.array([[1., 0.], [0., 1.], [0., 0.], [0., 0.]])
+    silence = np.zeros((4, 2))
+    eq(ring.peek_extend(audio), np.zeros((4, 2)))
+    eq(ring.peek_extend(silence), [[0, 0], [0, 0], [0, 0], [1, 0]])
+    eq(ring.peek_extend(silence), [[0, 1], [0, 0], [0, 0], [0, 0]])
+    ring = RingBuffer(7, bufferSize=4)       # shortening a line that holds samples
+    impulse, silence = np.array([1., 0., 0., 0.]), np.zeros(4)
+    eq(ring.peek_extend(impulse), [0, 0, 0, 0])
+    eq(ring.peek_extend(silence), [0, 0, 0, 1])
+    eq(ring.peek_extend(silence), [0, 0, 0, 0])
+    ring.length = 5
+    ring.pos = 2
+    eq(ring.peek_extend(silence), [0, 0, 0, 0])
+    eq(ring.peek_extend(impulse), [0, 0, 0, 0])
+    eq(ring.peek_extend(silence), [0, 1, 0, 0])
