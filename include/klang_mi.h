@@ -391,10 +391,12 @@ int klmi_kick_state_get(klmi_kick *kick, double *host_time /* [count] */,
 
 /* ---- chirp oscillators: klang.audio.oscillators.Chirper, x count ------------- */
 /* oscillators.py:280-308: wave_func(chirp_phase(t, startFrequency, duration, endFrequency,
- * method)) with scipy.signal's _chirp_phase (vertex_zero=True) and the chirper's own time
- * vector t (starts as DT * arange(256), gains DT * 256 per element and buffer; _reset puts
- * it back).  wave: klmi_wave sine..triangle.  Invalid combinations fail with scipy's
- * messages (logarithmic: f0 * f1 <= 0; hyperbolic: a zero frequency).
+ * method)); chirp_phase (oscillators.py:18-38) is scipy.signal's _chirp_phase
+ * (vertex_zero=True) until `duration` and the end frequency held from there on; t is the
+ * chirper's own time vector (starts as DT * arange(256), gains DT * 256 per element and
+ * buffer; _reset puts it back).  wave: klmi_wave sine..triangle.  Combinations that reach
+ * the sweep (duration > 0, start != end) and are invalid there fail with scipy's messages
+ * (logarithmic: f0 * f1 <= 0; hyperbolic: a zero frequency).
  * klmi_chirp_render = update() x n_blocks -> float64[count][n_blocks*256]. */
 typedef enum {
     KLMI_CHIRP_LINEAR = 0,

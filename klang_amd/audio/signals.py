@@ -208,10 +208,27 @@ class PwmOscillator(Phasor):
         return dict(super()._ctor_kwargs(), dutyCycle=self.dutyCycle.value)
 
 
-def chirp_phase(t, f0, t1, f1, method='linear'):
+def chirp_phase(t, freqStart, tEnd, freqEnd, method='linear'):
+    """Chirp phase with the constant-frequency extension for t >= tEnd
+    (klang/audio/oscillators.py:18-38): a buffer that starts at or after tEnd (or a sweep with
+    equal ends) is TAU * freqEnd * t with no offset, a buffer that straddles tEnd continues
+    the sweep's phase from its first sample at or after tEnd."""
+    t = np.asarray(t, dtype=float)
+    if tEnd <= t[0] or freqStart == freqEnd:
+        return TAU * freqEnd * t
+    phase = sweep_phase(t, freqStart, tEnd, freqEnd, method)
+    if t[-1] < tEnd:
+        return phase
+    mid = (t >= tEnd).argmax()
+    offset = phase[mid] - TAU * freqEnd * t[mid]
+    phase[mid:] = TAU * freqEnd * t[mid:] + offset
+    return phase
+
+
+def sweep_phase(t, f0, t1, f1, method='linear'):
     """Phase of a frequency sweep from f0 (at t = 0) to f1 (at t = t1): scipy.signal's
     `_chirp_phase` with vertex_zero=True, which the reference imports
-    (klang/audio/oscillators.py:3, 298-304), restated so that no private SciPy name is needed."""
+    (klang/audio/oscillators.py:3, 27), restated so that no private SciPy name is needed."""
     t = np.asarray(t)
     f0, t1, f1 = float(f0), float(t1), float(f1)
     if method in ('linear', 'lin', 'li'):

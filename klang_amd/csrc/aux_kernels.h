@@ -141,8 +141,9 @@ __global__ __launch_bounds__(kBlock) void kick_kernel(int count, int n_blocks,
         time_state[k] = time;
 }
 
-// klang.audio.oscillators.Chirper x count (oscillators.py:280-308) over scipy.signal's
-// _chirp_phase (vertex_zero=True).  One workgroup of 256 threads = one chirper, thread =
+// klang.audio.oscillators.Chirper x count (oscillators.py:280-308) over chirp_phase
+// (oscillators.py:18-38): scipy.signal's _chirp_phase (vertex_zero=True) until tEnd, the end
+// frequency held after it.  One workgroup of 256 threads = one chirper, thread =
 // sample position; every thread owns one element of the chirper's time vector, which gains
 // DT * BUFFER_SIZE per buffer (a float64 running sum per element, as `self.t += ...`).
 // par: [3][count] startFrequency, duration, endFrequency; kind: [2][count] method, wave;
@@ -158,32 +159,45 @@ __global__ __launch_bounds__(kBlock) void chirp_kernel(int count, int n_blocks,
     const int k = blockIdx.x, i = threadIdx.x;
     const double f0 = par[k], t1 = par[count + k], f1 = par[2 * (size_t)count + k];
     const int method = kind[k], wave = kind[count + k];
+    const double w1 = kTau * f1;
+    __shared__ double t_sh[kBlock];
+    __shared__ double offset_sh;
     double t = t_state[(size_t)k * kBlock + i];
     for (int b = 0; b < n_blocks; ++b) {
+        t_sh[i] = t;
+        __syncthreads();
+        const double t_first = t_sh[0], t_last = t_sh[kBlock - 1];
         double p;
-        if (method == CHIRP_QUADRATIC) {
-            const double beta = (f1 - f0) / (t1 * t1);
-            p = kTau * (f0 * t + beta * pow(t, 3.) / 3.);
-        } else if (method == CHIRP_LOGARITHMIC) {
-            if (f0 == f1) {
-                p = kTau * f0 * t;
-            } else {
+        if (t1 <= t_first || f0 == f1) {
+            p = w1 * t;   // oscillators.py:23-25: held frequency, no offset
+        } else {
+            if (method == CHIRP_QUADRATIC) {
+                const double beta = (f1 - f0) / (t1 * t1);
+                p = kTau * (f0 * t + beta * pow(t, 3.) / 3.);
+            } else if (method == CHIRP_LOGARITHMIC) {
                 const double beta = t1 / log(f1 / f0);
                 p = kTau * beta * f0 * (pow(f1 / f0, t / t1) - 1.0);
-            }
-        } else if (method == CHIRP_HYPERBOLIC) {
-            if (f0 == f1) {
-                p = kTau * f0 * t;
-            } else {
+            } else if (method == CHIRP_HYPERBOLIC) {
                 const double sing = -f1 * t1 / (f0 - f1);
                 p = kTau * (-sing * f0) * log(fabs(1 - t / sing));
+            } else {
+                const double beta = (f1 - f0) / t1;
+                p = kTau * (f0 * t + 0.5 * beta * t * t);
             }
-        } else {
-            const double beta = (f1 - f0) / t1;
-            p = kTau * (f0 * t + 0.5 * beta * t * t);
+            if (!(t_last < t1)) {
+                // oscillators.py:33-37: this buffer straddles tEnd (uniform over the
+                // workgroup); the first sample at or after it hands its phase on
+                const bool held = t >= t1;
+                if (held && !(t_sh[i - 1] >= t1))   // i > 0 here: t_first < t1
+                    offset_sh = p - w1 * t;
+                __syncthreads();
+                if (held)
+                    p = w1 * t + offset_sh;
+            }
         }
         out[((size_t)k * n_blocks + b) * kBlock + i] = wave_eval_any(wave, p, kPi);
         t = t + kDt * kBlock;   // oscillators.py:308
+        __syncthreads();        // t_sh and offset_sh are rewritten by the next buffer
     }
     t_state[(size_t)k * kBlock + i] = t;
 }

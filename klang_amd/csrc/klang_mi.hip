@@ -2323,6 +2323,10 @@ extern "C" int klmi_chirp_create(klmi_ctx *ctx, int count, const double *start_f
         if (wave[k] < KLMI_WAVE_SINE || wave[k] > KLMI_WAVE_TRIANGLE)
             return fail(KLMI_E_ARG, "klmi_chirp_create: wave id %d (sine, square, sawtooth, "
                                     "triangle are 0..3)", wave[k]);
+        // the sweep formula is only reached by a chirper whose first buffer starts before
+        // tEnd and whose ends differ (oscillators.py:23-25); the others never raise
+        if (!(duration[k] > 0.) || f0 == f1)
+            continue;
         if (method[k] == KLMI_CHIRP_LOGARITHMIC && f0 * f1 <= 0.0)
             return fail(KLMI_E_ARG, "For a logarithmic chirp, f0 and f1 must be nonzero and have "
                                     "the same sign.");

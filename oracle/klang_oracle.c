@@ -924,7 +924,8 @@ void ko_kick_block(ko_kick *k, int trigger, double *out)
 }
 
 /* ------------------------------------------------------------------------ */
-/* oscillators.py:280-308 Chirper over scipy.signal's _chirp_phase (scipy 1.15.3
+/* oscillators.py:280-308 Chirper over chirp_phase (oscillators.py:18-38), which is
+ * scipy.signal's _chirp_phase with a held frequency from tEnd on (scipy 1.15.3
  * scipy/signal/_waveforms.py, vertex_zero=True; un-vendored: restated from its source as
  * installed in the survey container).  The chirper's time vector starts as T and gains
  * DT * BUFFER_SIZE per element and buffer (a float64 running sum per element). */
@@ -932,7 +933,13 @@ void ko_chirp_block(ko_chirper *c, double *out)
 {
     const double f0 = c->f0, t1 = c->t1, f1 = c->f1;
     double phase[KO_BUFFER_SIZE];
+    /* oscillators.py:23-25: past the sweep (or equal ends): constant frequency, no offset */
+    const int constant = (t1 <= c->t[0]) || (f0 == f1);
     for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
+        if (constant) {
+            phase[i] = KO_TAU * f1 * c->t[i];
+            continue;
+        }
         const double t = c->t[i];
         double p;
         switch (c->method) {
@@ -964,6 +971,16 @@ void ko_chirp_block(ko_chirper *c, double *out)
         }
         }
         phase[i] = p;
+    }
+    if (!constant && !(c->t[KO_BUFFER_SIZE - 1] < t1)) {
+        /* oscillators.py:33-37: the buffer straddles tEnd; from the first sample at or after
+         * it the frequency is held and the sweep's phase there carries on */
+        int mid = 0;
+        while (!(c->t[mid] >= t1))
+            ++mid;
+        const double offset = phase[mid] - KO_TAU * f1 * c->t[mid];
+        for (int i = mid; i < KO_BUFFER_SIZE; ++i)
+            phase[i] = KO_TAU * f1 * c->t[i] + offset;
     }
     ko_wave(c->wave, phase, KO_BUFFER_SIZE, .5, out);
     const double step = (1. / KO_SAMPLING_RATE) * KO_BUFFER_SIZE; /* oscillators.py:308 */

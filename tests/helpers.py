@@ -81,3 +81,19 @@ REPORT = {}
 def report(block_type, err):
     REPORT[block_type] = max(REPORT.get(block_type, 0.), float(err))
     return err
+
+
+# Chirper fixtures (tests/golden/chirper.npz): name, constructor arguments, wave, tolerance.
+# Linear sweeps are plain float64 arithmetic (non-sine waves bit-exact, sine within libm
+# ulps); pow / log sweeps differ by libm ulps inside a phase of a few thousand radians.  The
+# last four cover chirp_phase's held region (oscillators.py:18-38); all ten run past tEnd.
+CHIRPS = [('linear_sine', (100., .4, 2000., 'linear'), 'sine', 1e-12),
+          ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth', 0.),
+          ('linear_square', (30., .5, 900., 'linear'), 'square', 0.),
+          ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine', 1e-9),
+          ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine', 1e-9),
+          ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine', 1e-9),
+          ('equal_ends', (300., .2, 300., 'linear'), 'sine', 1e-12),
+          ('no_sweep', (100., 0., 500., 'linear'), 'sawtooth', 0.),
+          ('short_log', (100., .003, 900., 'logarithmic'), 'sine', 1e-9),
+          ('short_hyp', (900., .01, 100., 'hyperbolic'), 'triangle', 1e-9)]

@@ -5,7 +5,7 @@ Everything goes through the C-ABI."""
 import numpy as np
 import pytest
 
-from tests.helpers import B, oracle_synth_bank, report, synth_notes
+from tests.helpers import B, CHIRPS, oracle_synth_bank, report, synth_notes
 
 pytestmark = pytest.mark.gpu
 
@@ -220,28 +220,20 @@ def test_many_kicks_vs_oracle(hip, ctx, oracle):
 
 
 # ---- Chirper (oscillators.py:280-308) --------------------------------------------------------
-CHIRPS = [('linear_sine', (100., .4, 2000., 'linear'), 'sine', 1e-12),
-          ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth', 0.),
-          ('linear_square', (30., .5, 900., 'linear'), 'square', 0.),
-          ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine', 1e-9),
-          ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine', 1e-9),
-          ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine', 1e-9)]
-
-
 def test_chirp_batch_vs_reference(hip, ctx, golden):
-    """All six fixtures as ONE batch, rendered in three calls.  Linear sweeps are plain
-    float64 arithmetic: non-sine waves bit-exact; pow / log sweeps differ by libm ulps inside
-    a phase of a few thousand radians."""
+    """All ten fixtures as ONE batch, rendered in four calls; every one runs past its tEnd
+    into the held region (tolerances: tests/helpers.py CHIRPS)."""
     g = golden('chirper')
-    waves = {'sine': hip.WAVE_SINE, 'sawtooth': hip.WAVE_SAWTOOTH, 'square': hip.WAVE_SQUARE}
+    waves = {'sine': hip.WAVE_SINE, 'sawtooth': hip.WAVE_SAWTOOTH, 'square': hip.WAVE_SQUARE,
+             'triangle': hip.WAVE_TRIANGLE}
     batch = hip.ChirpBatch(ctx, [c[1][0] for c in CHIRPS], [c[1][1] for c in CHIRPS],
                            [c[1][2] for c in CHIRPS], [c[1][3] for c in CHIRPS],
                            [waves[c[2]] for c in CHIRPS])
-    out = np.concatenate([batch.render(k) for k in (1, 9, 30)], axis=1)
+    out = np.concatenate([batch.render(k) for k in (1, 9, 30, 60)], axis=1)
     t = batch.time_vectors()
     for i, (name, _, _, tol) in enumerate(CHIRPS):
         want = g[name].ravel()
-        report('Chirper %s (float64 out)' % name.split('_')[0], np.abs(out[i] - want).max())
+        report('Chirper %s (float64 out)' % name, np.abs(out[i] - want).max())
         if tol:
             assert np.abs(out[i] - want).max() <= tol, name
         else:
@@ -255,6 +247,7 @@ def test_chirp_batch_vs_reference(hip, ctx, golden):
     assert 'same sign' in str(e.value)
     with pytest.raises(hip.NativeError):
         hip.ChirpBatch(ctx, [0.], [1.], [100.], 'hyperbolic')
+    hip.ChirpBatch(ctx, [100.], [0.], [-100.], 'logarithmic').close()   # never sweeps: no error
     with pytest.raises(ValueError):
         hip.ChirpBatch(ctx, [10.], [1.], [100.], 'cubic')
 

@@ -388,3 +388,140 @@ def test_ring_buffer_as_delay_line():
     eq(ring.peek_extend(silence), [0, 0, 0, 0])
     eq(ring.peek_extend(impulse), [0, 0, 0, 0])
     eq(ring.peek_extend(silence), [0, 1, 0, 0])
+
+
+def test_audio_helper_known_answers():
+    """tests/test_audio.py:9-47 restated: silence and time arrays are read-only."""
+    from klang_amd.audio.signals import get_silence, get_time
+    mono = get_silence(10)
+    assert mono.shape == (10,) and not mono.any()
+    with pytest.raises(ValueError):
+        mono[0] = 1
+    stereo = get_silence((2, 10))
+    assert stereo.shape == (2, 10) and not stereo.any()
+    with pytest.raises(ValueError):
+        stereo[0, 0] = 1
+    t = get_time(10, .1)
+    np.testing.assert_array_equal(t, .1 * np.arange(10))
+    with pytest.raises(ValueError):
+        t[0] = 1
+
+
+def test_linear_mapping_hits_both_ends():
+    """tests/test_math.py:6-15."""
+    from klang_amd.audio.signals import linear_mapping
+    a, b = linear_mapping((-1, 2), (-2, 3))
+    assert a * -1 + b == -2 and a * 2 + b == 3
+
+
+def test_note_durations():
+    """tests/test_tempo.py:20-25, with the 4/4 metre the reference's constants name."""
+    from fractions import Fraction
+    from klang_amd.tempo import compute_duration, compute_rate, note_duration
+    four_four = Fraction(4, 4, _normalize=False)
+    for value, want in [(Fraction(1, 8), .25), (Fraction(1, 4), .5), (Fraction(1, 2), 1.),
+                        (Fraction(1, 1), 2.)]:
+        assert note_duration(value, 120, four_four) == want
+        assert compute_duration(value, 120, four_four) == want
+        assert compute_rate(value, 120, four_four) == 1. / want
+    assert compute_duration(.3) == .3 and compute_rate(5.) == 5.
+
+
+def test_find_next_primes():
+    """tests/test_primes.py:8-54: the primes under 100, from any start."""
+    from klang_amd.audio.filtering import find_next_primes
+    under_100 = [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73,
+                 79, 83, 89, 97]
+    assert find_next_primes(25, start=-10) == under_100
+    for start in range(-10, 97):
+        want = next(p for p in under_100 if p >= start)
+        assert find_next_primes(1, start) == [want]
+    assert find_next_primes(3, 90) == [97, 101, 103]
+
+
+def test_note_dict_conversion():
+    """tests/test_messages.py:14-22."""
+    dct = Note(pitch=60).to_dict()
+    assert (dct['pitch'], dct['velocity'], dct['type']) == (60, 1., 'Note')
+    assert Note.from_dict(dct) == Note(pitch=60)
+    assert Note.from_json(Note(pitch=69).to_json()) == Note(pitch=69)
+
+
+def test_chirp_phase_properties():
+    """tests/test_audio_oscillators.py:11-58: frequency and sweep rate of the chirp phase."""
+    from klang_amd.audio.signals import chirp_phase
+    from klang_amd.constants import TAU
+    for lo, hi in ((0., 1.), (1., 2.)):   # inside the sweep and in the held region after it
+        t, dt = np.linspace(lo, hi, 10, endpoint=False, retstep=True)
+        omega = np.diff(chirp_phase(t, 1.234, 1., 1.234)) / dt
+        np.testing.assert_almost_equal(omega / TAU, 1.234)
+    t, dt = np.linspace(0, 1., 128, endpoint=False, retstep=True)
+    omega = np.diff(chirp_phase(t, 2., 1., 3., method='linear')) / dt
+    np.testing.assert_allclose(np.diff(omega) / dt, TAU)
+    t, dt = np.linspace(0, 1., 128, retstep=True)
+    np.testing.assert_allclose(np.diff(chirp_phase(t, 1., 1., 2.), n=2) / dt**2, TAU)
+    t, dt = np.linspace(1., 10., 128, retstep=True)
+    np.testing.assert_allclose(np.diff(chirp_phase(t, 1., 1., 2.), n=2) / dt**2, 0., atol=1e-10)
+    t = np.linspace(0, 2., 128)
+    assert (np.diff(chirp_phase(t, 1., 1., 2.)) < .2).all()
+
+
+def test_sample_phase_known_answers():
+    """tests/test_audio_oscillators.py:60-112."""
+    from klang_amd.audio.signals import DT, INTERVAL, sample_phase
+    from klang_amd.config import BUFFER_SIZE
+    from klang_amd.constants import TAU
+    n = np.arange(BUFFER_SIZE)
+    phase, _ = sample_phase(440.)
+    np.testing.assert_almost_equal(phase, TAU * 440. * DT * n % TAU)
+    freqs = np.linspace(440., 880., BUFFER_SIZE)
+    phase, _ = sample_phase(freqs)
+    want = np.zeros(BUFFER_SIZE)
+    want[1:] = TAU * DT * np.cumsum(freqs[:-1])
+    np.testing.assert_almost_equal(phase, want % TAU)
+    assert sample_phase(440., 1.234)[0][0] == 1.234
+    assert sample_phase(freqs, 1.234)[0][0] == 1.234
+    phase, _ = sample_phase(2 / INTERVAL)                      # two cycles per buffer
+    np.testing.assert_almost_equal(phase, np.linspace(0, 2 * TAU, BUFFER_SIZE, endpoint=False) % TAU)
+    assert sample_phase(1 / INTERVAL)[1] == 0.                 # one cycle: back to zero
+
+
+def test_phasor_and_oscillator_known_answers():
+    """tests/test_audio_oscillators.py:114-157."""
+    from klang_amd.audio import Phasor
+    from klang_amd.audio.signals import DT, INTERVAL
+    from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
+    from klang_amd.constants import TAU
+    phasor = Phasor(frequency=.5)
+    assert phasor.currentPhase == 0.
+    phasor.update()
+    assert phasor.currentPhase == TAU * .5 * INTERVAL
+    phasor = Phasor(frequency=10.)
+    cycles = int((SAMPLING_RATE / 10.) // BUFFER_SIZE) + 1
+    for _ in range(cycles):
+        phasor.update()
+    assert abs(phasor.currentPhase - cycles * TAU * 10. * INTERVAL % TAU) < 1e-7
+    phasor = Phasor(frequency=.25 / INTERVAL)
+    assert [phasor.sample() for _ in range(5)] == [0., .25 * TAU, .5 * TAU, .75 * TAU, 0.]
+    osc = Oscillator(frequency=440.)
+    osc.update()
+    np.testing.assert_almost_equal(osc.output.value, np.sin(TAU * 440. * DT * np.arange(BUFFER_SIZE)))
+
+
+def test_voice_known_answers():
+    """tests/test_audio_voices.py:19-77 with ADSR(0, 0, 1, 0)."""
+    from klang_amd.audio import PwmOscillator
+    voice = Voice(Oscillator(), ADSR(0., 0., 1., 0.))
+    assert not voice.active and voice.amplitude == 0
+    voice.update()
+    assert not voice.output.value.any()
+    voice.input.push(Note(60, velocity=.5))
+    assert voice.active
+    voice.update()
+    assert voice.active and voice.amplitude == .5 and (voice.output.value != 0.).all()
+    voice.input.push(Note(60, velocity=0.))
+    voice.update()
+    assert not voice.active and voice.amplitude == .5
+    osc, lfo, env = PwmOscillator(), Oscillator(), ADSR()
+    lfo.output.connect(osc.dutyCycle)
+    assert Voice(osc, env).execOrder == [env, lfo, osc]

@@ -19,6 +19,7 @@ from klang_amd.errors import KlangError
 from klang_amd.klang import run_klang
 from klang_amd.messages import Note
 from klang_amd.schedule import determine_execution_order
+from tests.helpers import CHIRPS
 
 B = 256
 DT = 1. / 44100
@@ -414,17 +415,14 @@ def test_find_fusable_synthesizers():
 
 
 def test_host_chirper_and_kick_vs_golden(golden):
-    """Chirper (oscillators.py:280-308, scipy's _chirp_phase restated) and Kick
+    """Chirper (oscillators.py:280-308, chirp_phase with its held region) and Kick
     (synthesizer.py:253-283) as host blocks: the same NumPy operations as the reference."""
-    from klang_amd.audio import Chirper, Kick, sawtooth, sine, square
+    from klang_amd.audio import Chirper, Kick, sawtooth, sine, square, triangle
     from klang_amd.messages import Note
     g = golden('chirper')
-    for name, args, wave in (('linear_sine', (100., .4, 2000., 'linear'), sine),
-                             ('linear_saw', (2000., .3, 50., 'linear'), sawtooth),
-                             ('linear_square', (30., .5, 900., 'linear'), square),
-                             ('quadratic_sine', (100., .4, 2000., 'quadratic'), sine),
-                             ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), sine),
-                             ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), sine)):
+    waves = dict(sine=sine, sawtooth=sawtooth, square=square, triangle=triangle)
+    for name, args, wname, _ in CHIRPS:
+        wave = waves[wname]
         ch = Chirper(*args, wave_func=wave)
         out = []
         for _ in range(len(g[name])):
@@ -438,6 +436,8 @@ def test_host_chirper_and_kick_vs_golden(golden):
         Chirper(100., 1., -100., 'logarithmic').update()
     with pytest.raises(ValueError):
         Chirper(100., 1., 200., 'cubic').update()
+    Chirper(100., 0., -100., 'logarithmic').update()   # never reaches the sweep: no error
+    Chirper(0., 1., 0., 'hyperbolic').update()
     s = golden('synthesizer')
     kick = Kick()
     hits = {0: Note(36), 30: Note(36, 0.), 70: Note(36)}

@@ -10,6 +10,8 @@ form)."""
 import numpy as np
 import pytest
 
+from tests.helpers import CHIRPS
+
 B = 256
 TAU = 2. * np.pi
 DT = 1. / 44100
@@ -638,14 +640,7 @@ def test_kick_drum(oracle, golden, name, kw, triggers):
     np.testing.assert_allclose(kick.current_phase, g[name + '_final'][1:], rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize('name,args,wave,tol', [
-    ('linear_sine', (100., .4, 2000., 'linear'), 'sine', 1e-12),   # exact phase, sine ulps
-    ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth', 0.),
-    ('linear_square', (30., .5, 900., 'linear'), 'square', 0.),
-    ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine', 1e-9),      # pow / log of another
-    ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine', 1e-9),  # libm inside a phase
-    ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine', 1e-9),    # of a few thousand rad
-])
+@pytest.mark.parametrize('name,args,wave,tol', CHIRPS, ids=[c[0] for c in CHIRPS])
 def test_chirper(oracle, golden, name, args, wave, tol):
     g = golden('chirper')
     want = g[name]

@@ -119,17 +119,23 @@ def main():
          lfo_scale_offset=np.array([lfo_s.scale, lfo_s.offset, lfo_v.scale, lfo_v.offset]),
          **wav)
 
-    # ---- Chirper (oscillators.py:280-308) over scipy's _chirp_phase ----------
+    # ---- Chirper (oscillators.py:280-308) over chirp_phase (oscillators.py:18-38) ----
     chirp = {}
     for name, args, wname in (('linear_sine', (100., .4, 2000., 'linear'), 'sine'),
                               ('linear_saw', (2000., .3, 50., 'linear'), 'sawtooth'),
                               ('linear_square', (30., .5, 900., 'linear'), 'square'),
                               ('quadratic_sine', (100., .4, 2000., 'quadratic'), 'sine'),
                               ('logarithmic_sine', (100., .4, 2000., 'logarithmic'), 'sine'),
-                              ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine')):
+                              ('hyperbolic_sine', (100., .4, 2000., 'hyperbolic'), 'sine'),
+                              # the held region of chirp_phase (oscillators.py:18-38): equal
+                              # ends, no sweep at all, a sweep that ends inside buffer 0
+                              ('equal_ends', (300., .2, 300., 'linear'), 'sine'),
+                              ('no_sweep', (100., 0., 500., 'linear'), 'sawtooth'),
+                              ('short_log', (100., .003, 900., 'logarithmic'), 'sine'),
+                              ('short_hyp', (900., .01, 100., 'hyperbolic'), 'triangle')):
         ch = OSC.Chirper(*args, wave_func=W.WAVE_FUNCTIONS[wname])
         blocks = []
-        for b in range(40):
+        for b in range(100):   # .58 s: every sweep above ends inside
             ch.update()
             blocks.append(np.array(ch.output.value, dtype=float))
         chirp[name] = np.array(blocks)
