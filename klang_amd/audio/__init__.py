@@ -9,13 +9,13 @@ from klang_amd.audio.effects import (Bitcrusher, Delay, Gain, OctaveDistortion, 
                                      Subsampler, TanhDistortion, Transformer, Tremolo)
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.voices import Voice
-from klang_amd.audio.synthesizer import (Kick, MonophonicSynthesizer, NoteScheduler,
+from klang_amd.audio.synthesizer import (HiHat, Kick, MonophonicSynthesizer, NoteScheduler,
                                          PolyphonicSynthesizer, Synthesizer)
 from klang_amd.audio.engine import Adc, Dac, run_audio_engine, write_wave
 
 __all__ = ['Chirper', 'FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscillator', 'WAVE_FUNCTIONS', 'sample_phase',
            'sawtooth', 'sine', 'square', 'triangle', 'ADSR', 'AR', 'D', 'R', 'Envelope',
            'BackwardCombFilter', 'EchoFilter', 'Filter', 'ForwardCombFilter', 'Reverb', 'Mixer',
-           'StereoMixer', 'Voice', 'Kick', 'MonophonicSynthesizer', 'NoteScheduler', 'PolyphonicSynthesizer',
+           'StereoMixer', 'Voice', 'HiHat', 'Kick', 'MonophonicSynthesizer', 'NoteScheduler', 'PolyphonicSynthesizer',
            'Synthesizer', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
            'Transformer', 'Tremolo', 'Bitcrusher', 'RingModulator', 'Subsampler', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']

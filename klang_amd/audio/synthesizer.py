@@ -7,8 +7,9 @@ a sequential heap per instrument.
 
 ``Kick`` is mirrored with the reference's behaviour as it is: its
 ``currentPhase`` turns into a 256-vector after the first buffer
-(synthesizer.py:282 with waves.py:61).  Not mirrored: ``HiHat`` (white noise
-from NumPy's global RNG: no parity is possible).
+(synthesizer.py:282 with waves.py:61).  ``HiHat`` is a host block only: its white
+noise comes from NumPy's global RNG, so it matches the reference exactly when the caller
+seeds ``np.random`` the same way, and there is no device form of that stream.
 """
 import copy
 import heapq
@@ -24,7 +25,7 @@ from klang_amd.block import Block
 from klang_amd.wiring import MessageInput
 
 __all__ = ['NoteScheduler', 'Synthesizer', 'MonophonicSynthesizer', 'PolyphonicSynthesizer',
-           'Kick']
+           'HiHat', 'Kick']
 
 
 def duplicate_voice(voice, number):
@@ -161,6 +162,30 @@ def sample_pitch_decay(frequency, decay, intensity, t0=0.):
     """synthesizer.py:39-55."""
     env, t1 = sample_exponential_decay(decay, t0)
     return frequency * (1. + intensity * env), t1
+
+
+class HiHat(Block):
+    """White noise under a decay envelope (synthesizer.py:222-250).  The noise is drawn from
+    NumPy's global RandomState once per buffer (or once for good with ``loopedNoise``), in the
+    reference's order: construction first, then one draw per update."""
+
+    def __init__(self, decay=.05, loopedNoise=False):
+        from klang_amd.audio.envelopes import D
+        super().__init__(nOutputs=1)
+        self.inputs = [MessageInput(self)]
+        if loopedNoise:
+            noise = 2 * np.random.random(BUFFER_SIZE) - 1.
+            self.noise_generator = lambda: noise
+        else:
+            self.noise_generator = lambda: 2 * np.random.random(BUFFER_SIZE) - 1.
+        self.envelope = D(decay)
+
+    def update(self):
+        for note in self.input.receive():
+            self.envelope.input.push(note)
+        self.envelope.update()
+        env = self.envelope.output.get_value()
+        self.output.set_value(env * self.noise_generator())
 
 
 class Kick(Block):

@@ -449,3 +449,29 @@ def test_host_chirper_and_kick_vs_golden(golden):
         out.append(np.array(kick.output.value))
     np.testing.assert_array_equal(np.array(out), s['kick_default_out'])
     np.testing.assert_array_equal(np.r_[kick.currentTime, kick.currentPhase], s['kick_default_final'])
+
+
+def test_host_hihat_vs_golden_with_the_same_seed(golden):
+    """HiHat (synthesizer.py:222-250) is a D envelope times white noise from NumPy's global
+    RandomState: with the seed the fixture was made with, the host block is bit-exact.  It has
+    no device form (HOT_PATH_TYPES leaves it out): a graph with a HiHat keeps it on the host."""
+    from klang_amd.audio import HiHat
+    s = golden('synthesizer')
+    state = np.random.get_state()
+    try:
+        for name, seed, kw in (('hihat_fresh', 1234, {}),
+                               ('hihat_looped', 99, dict(decay=.12, loopedNoise=True))):
+            np.random.seed(seed)
+            hat = HiHat(**kw)
+            out = []
+            for b in range(60):
+                if b in (2, 30):
+                    hat.input.push(Note(42))
+                if b == 35:
+                    hat.input.push(Note(42, 0.))
+                hat.update()
+                out.append(np.array(hat.output.value))
+            np.testing.assert_array_equal(np.array(out), s[name + '_out'])
+    finally:
+        np.random.set_state(state)
+    assert HiHat not in fusion.HOT_PATH_TYPES

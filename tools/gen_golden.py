@@ -612,6 +612,22 @@ def main():
                 outs.append(np.array(kick.output.value, dtype=float))
         syn[name + '_out'] = np.array(outs)
         syn[name + '_final'] = np.r_[kick.currentTime, np.broadcast_to(kick.currentPhase, (B,))]
+    # HiHat (synthesizer.py:222-250): D envelope x white noise from NumPy's GLOBAL legacy
+    # RandomState, seeded here (MT19937 via np.random.seed: a stable stream) so that a host
+    # block that draws in the same order can be compared
+    for name, seed, kw in (('hihat_fresh', 1234, {}),
+                           ('hihat_looped', 99, dict(decay=.12, loopedNoise=True))):
+        np.random.seed(seed)
+        hat = SY.HiHat(**kw)
+        outs = []
+        for b in range(60):
+            if b in (2, 30):
+                hat.input.push(E(42))
+            if b == 35:
+                hat.input.push(E(42, 0.))
+            hat.update()
+            outs.append(np.array(hat.output.value, dtype=float))
+        syn[name + '_out'] = np.array(outs)
     syn['template'] = np.array([.004, .02, .6, .012])
     save('synthesizer', **syn)
 
