@@ -4,10 +4,11 @@ Block / | / + code, `from klang...` replaced by `from klang_amd...`.  Every modu
 
     python -m examples.hello_world [out.wav]
 
-Message sources of the reference that are control plane and not part of this package
-(Sequencer, MusicalKeyboard) are replaced by `klang_amd.notes.NoteScript`, a block that sends
-pre-written notes at given buffer numbers; under backend='hip' an offline bounce hands the
-whole script to the device up front."""
+The reference's Sequencer and Arpeggiator are mirrored (klang_amd.sequencing) and used as they
+are; its live sources (MusicalKeyboard, MIDI) are replaced by `klang_amd.notes.NoteScript`, a
+block that sends pre-written notes at given buffer numbers.  Under backend='hip' an offline
+bounce runs all of these ahead of the audio and hands the whole piece's notes to the device up
+front (klang_amd.klang.preschedule)."""
 from klang_amd.notes import NoteScript  # noqa: F401  (the examples import it from here)
 
 

@@ -13,6 +13,7 @@ import logging
 from klang_amd.audio.engine import (Adc, Dac, look_for_audio_blocks, run_audio_engine,  # noqa: F401
                                     write_pcm)
 from klang_amd.composite import Composite
+from klang_amd.audio.signals import INTERVAL
 from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
 from klang_amd.constants import INF
 from klang_amd.errors import KlangError
@@ -72,37 +73,56 @@ def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', of
 
 
 def preschedule(execOrder, banks, n_cycles):
-    """Event pre-computation for an offline bounce: when every message
-    source of the order is a NoteScript whose notes all go to device blocks, queue the whole
-    piece's notes on the device now -- each with the buffer it belongs to, in the order the
-    sources would have sent them -- and drop the sources from the order.  Nothing on the host
-    is left to run between buffers, so the banks may render ahead (or bounce the piece in one
-    pass).  Returns the order to execute."""
-    from klang_amd.notes import NoteScript
-    from klang_amd.wiring import MessageInput
-    sources = [b for b in execOrder if isinstance(b, NoteScript)]
-    if not sources or n_cycles is None:
+    """Event pre-computation for an offline bounce.  The host blocks that
+    feed notes to the device (NoteScript, Sequencer, Arpeggiator, note effects: anything
+    upstream of a device message input) are run for the whole piece NOW, under the clock the
+    engine will keep (a running sum of INTERVAL from 0, klanggeber.py:232, 249), and what
+    arrives at every device message input in buffer k is queued on the device for buffer k.
+    The sources are then dropped from the order: nothing on the host is left to run between
+    buffers, so the banks may render ahead (or bounce the piece in one pass).
+
+    This is only done when that set of blocks is closed: nothing in it listens to the device
+    or the Adc, and nothing it sends goes anywhere but to itself or to device message inputs.
+    Otherwise the order is returned as it is and the sources run buffer by buffer."""
+    from klang_amd import fusion
+    from klang_amd.block import input_connections, output_connections
+    from klang_amd.clock import ClockMixin
+    if n_cycles is None:
         return execOrder
     targets = {}
     for bank in banks:
         for inp, handle in bank.message_targets().items():
             targets[inp] = (bank, handle)
-    for src in sources:
-        if src.buffer != 0 or any(dst not in targets for dst in src.output.outgoingConnections):
-            return execOrder
-    cap = MessageInput.MAX_MESSAGES     # a queue keeps the newest 50 notes of a buffer
-    for k in range(n_cycles):
-        arrivals = collections.OrderedDict()
-        for src in sources:
-            for note in src.script.get(k, ()):
-                for dst in src.output.outgoingConnections:
-                    arrivals.setdefault(dst, []).append(note)
-        for dst, notes in arrivals.items():
-            bank, handle = targets[dst]
-            for note in notes[-cap:]:
-                bank.schedule(handle, note, k)
-    for src in sources:
-        src.buffer = n_cycles
+    device = (fusion.GpuVoiceBank, fusion.GpuKick, fusion.GpuChirper, Adc, Dac)
+    hosts = [b for b in execOrder if not isinstance(b, device)]
+    # the host blocks upstream of a device message input
+    feeders = {inp.incomingConnection.owner for inp in targets if inp.incomingConnection}
+    sources, frontier = set(), [b for b in hosts if b in feeders]
+    while frontier:
+        block = frontier.pop()
+        if block in sources:
+            continue
+        sources.add(block)
+        frontier.extend(src.owner for src, _ in input_connections(block))
+    if not sources or not sources <= set(hosts):
+        return execOrder        # nothing to do, or a source listens to a device block
+    for block in sources:
+        for _, dst in output_connections(block):
+            if dst not in targets and dst.owner not in sources:
+                return execOrder
+    order = [b for b in execOrder if b in sources]
+    play_time = 0.
+    try:
+        for k in range(n_cycles):
+            ClockMixin.set_current_time(play_time)
+            for block in order:
+                block.update()
+            for inp, (bank, handle) in targets.items():
+                for note in inp.receive():      # the queue has kept the newest 50 of a buffer
+                    bank.schedule(handle, note, k)
+            play_time += INTERVAL
+    finally:
+        ClockMixin.set_current_time(0.)
     return [b for b in execOrder if b not in sources]
 
 

@@ -3,24 +3,19 @@
 import collections
 import json
 
-from klang_amd.config import KAMMERTON
-
-
-def equal_temperament_frequency(pitch, kammerton=KAMMERTON):
-    """MIDI pitch -> Hz in 12-tone equal temperament, A4 = pitch 69."""
-    return kammerton * 2. ** ((pitch - 69) / 12.)
+from klang_amd.tunings import EQUAL_TEMPERAMENT
 
 
 class Note(collections.namedtuple('Note', 'pitch velocity frequency')):
     """pitch (0..127), velocity (0..1; 0 is note-off), frequency in Hz."""
 
-    def __new__(cls, pitch, velocity=1.0, frequency=None):
+    def __new__(cls, pitch, velocity=1.0, frequency=None, temperament=EQUAL_TEMPERAMENT):
         if not 0 <= pitch < 128:
             raise ValueError('Invalid pitch %s!' % pitch)
         if not 0 <= velocity <= 1.:
             raise ValueError('Invalid velocity %s!' % velocity)
         if frequency is None:
-            frequency = equal_temperament_frequency(pitch)
+            frequency = temperament.pitch_2_frequency(pitch)
         if frequency < 0:
             raise ValueError('Invalid frequency %s!' % frequency)
         return super().__new__(cls, pitch, velocity, frequency)

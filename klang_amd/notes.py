@@ -1,11 +1,11 @@
 """Pre-written note events: the form in which a sequence reaches the device ahead of time.
 
-The reference's message sources (Sequencer, Arpeggiator, keyboard: klang/sequencer.py,
-klang/arpeggiator.py, klang/keyboard.py) are host control plane and emit their notes one
-buffer at a time.  A ``NoteScript`` holds the notes of a whole piece by buffer number, so an
-offline bounce can hand all of them to the device banks up front (klang_amd.klang.preschedule,
-SURVEY 8f rank 4) and render the piece in one pass; executed as an ordinary block it sends
-buffer k's notes while buffer k runs, like any other source.
+The reference's live message sources (keyboard, MIDI: klang/keyboard.py, klang/midi.py) have
+no place in an offline bounce.  A ``NoteScript`` holds the notes of a whole piece by buffer
+number; executed as an ordinary block it sends buffer k's notes while buffer k runs, like any
+other source, and like the mirrored Sequencer / Arpeggiator (klang_amd.sequencing) it is run
+ahead of the audio by klang_amd.klang.preschedule when its notes go to the
+device, so that the piece renders in one pass.
 """
 from klang_amd.block import Block
 from klang_amd.wiring import MessageOutput

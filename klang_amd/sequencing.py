@@ -1,0 +1,386 @@
+"""Note sources and note effects, host side: the pattern Sequencer (klang/sequencer.py:29-301),
+the Arpeggiator (klang/arpeggiator.py:24-194) and the note effects both rest on
+(klang/note_effects.py:11-91).
+
+These are the reference's control plane: small Python state machines that turn a phase or a
+held chord into Note messages, one buffer at a time.  They are mirrored here so that a patch
+written against the reference runs unchanged, and because their output over a whole offline
+bounce is a pure function of the buffer number: `klang_amd.klang.preschedule` runs them ahead
+of the audio, records which note reaches which device voice in which buffer, and hands the
+whole piece to the device banks up front ("event pre-computation").
+"""
+import bisect
+import collections
+import collections.abc
+import itertools
+import math
+import random
+
+import numpy as np
+
+from klang_amd.audio.signals import Phasor
+from klang_amd.block import Block
+from klang_amd.clock import ClockMixin
+from klang_amd.composite import Composite
+from klang_amd.constants import TAU
+from klang_amd.messages import Note
+from klang_amd.tempo import QUARTER_NOTE, SIXTEENTH_NOTE, compute_duration, tempo_2_period
+from klang_amd.wiring import MessageInput, MessageOutput, MessageRelay, Relay
+
+__all__ = ['NoteLengthener', 'MaxNotes', 'MessageMixer', 'random_pattern', 'pizza_slice_number',
+           'atleast_1d', 'atleast_2d', 'PizzaSlicer', 'PatternLookup', 'Sequence', 'Sequencer',
+           'VALID_ORDERS', 'interleave', 'arpeggio_index_permutation', 'Arpeggio',
+           'Arpeggiator']
+
+
+# ---- note effects (klang/note_effects.py) --------------------------------------------------
+
+class _MessageBlock(Block):
+    """One message input, one message output."""
+
+    def __init__(self):
+        super().__init__()
+        self.inputs = [MessageInput(owner=self)]
+        self.outputs = [MessageOutput(owner=self)]
+
+
+class NoteLengthener(_MessageBlock, ClockMixin):
+    """Turns note-ons into notes of `duration` seconds: the note-off follows once the clock
+    has reached its end time (note_effects.py:11-47).  Ends are kept in arrival order."""
+
+    def __init__(self, duration):
+        super().__init__()
+        self.duration = duration
+        self.activeNotes = collections.deque()   # (end time, note)
+
+    def outdated_notes(self, now):
+        while self.activeNotes and not now < self.activeNotes[0][0]:
+            yield self.activeNotes.popleft()[1]
+
+    def update(self):
+        now = self.clock()
+        for note in self.outdated_notes(now):
+            self.output.send(note.silence())
+        for note in self.input.receive():
+            if note.on:
+                self.activeNotes.append((now + self.duration, note))
+                self.output.send(note)
+
+
+class MaxNotes(_MessageBlock):
+    """At most `nNotes` sounding notes: a new note-on silences the oldest ones first
+    (note_effects.py:50-71)."""
+
+    def __init__(self, nNotes=1):
+        super().__init__()
+        self.nNotes = nNotes
+        self.activeNotes = collections.deque([], maxlen=nNotes + 1)
+
+    def update(self):
+        for note in self.input.receive():
+            if not note.on:
+                continue
+            self.activeNotes.append(note)
+            while len(self.activeNotes) > self.nNotes:
+                self.output.send(self.activeNotes.popleft().silence())
+            self.output.send(note)
+
+
+class MessageMixer(Block):
+    """Forwards the messages of all its inputs, input by input (note_effects.py:74-91)."""
+
+    def __init__(self, nInputs=2):
+        super().__init__()
+        self.outputs = [MessageOutput(owner=self)]
+        for _ in range(nInputs):
+            self.add_new_channel()
+
+    def add_new_channel(self):
+        self.inputs.append(MessageInput(owner=self))
+
+    def update(self):
+        for inp in self.inputs:
+            for message in inp.receive():
+                self.output.send(message)
+
+
+# ---- sequencer (klang/sequencer.py) --------------------------------------------------------
+
+def random_pattern(length, period=None, minVal=60, maxVal=72):
+    """`length` random pitches that repeat every `period` (sequencer.py:29-53; Python's
+    `random` module, one randint per period entry)."""
+    period = length if period is None else period
+    seed = [random.randint(minVal, maxVal) for _ in range(period)]
+    return list(itertools.islice(itertools.cycle(seed), length))
+
+
+def pizza_slice_number(angle, nSlices):
+    """Which of nSlices equal slices of the circle `angle` lies in (sequencer.py:56-66)."""
+    return int((angle % TAU) / TAU * nSlices)
+
+
+def _is_sequence(obj):
+    return isinstance(obj, collections.abc.Sequence)
+
+
+def atleast_1d(obj):
+    """np.atleast_1d for arrays; anything that is no sequence is packed into a list, ragged
+    lists stay as they are (sequencer.py:69-79)."""
+    if isinstance(obj, np.ndarray):
+        return np.atleast_1d(obj)
+    return obj if _is_sequence(obj) else [obj]
+
+
+def atleast_2d(obj):
+    """Same for two levels (sequencer.py:82-93)."""
+    if isinstance(obj, np.ndarray):
+        return np.atleast_2d(obj)
+    obj = atleast_1d(obj)
+    return obj if _is_sequence(obj[0]) else [obj]
+
+
+class PizzaSlicer(Block):
+    """Phase in [0, TAU) -> step numbers: sends every step index between the last one sent
+    and the one the phase is in now, wrapping around (sequencer.py:96-128)."""
+
+    def __init__(self, nSlices):
+        super().__init__(nInputs=1)
+        self.outputs = [MessageOutput(owner=self)]
+        self.nSlices = nSlices
+        self.currentIdx = -1
+
+    def increment(self):
+        self.currentIdx = (self.currentIdx + 1) % self.nSlices
+
+    def update(self):
+        target = pizza_slice_number(self.input.value, self.nSlices)
+        for _ in range((target - self.currentIdx) % self.nSlices):
+            self.increment()
+            self.output.send(self.currentIdx)
+
+
+class PatternLookup(_MessageBlock):
+    """Step number -> Note(s) of the pattern; a 0 / None / empty entry is a rest, a list entry a
+    chord (sequencer.py:131-151)."""
+
+    def __init__(self, pattern):
+        super().__init__()
+        self.pattern = pattern
+
+    def update(self):
+        for step in self.input.receive():
+            for pitch in atleast_1d(self.pattern[step]):
+                if pitch:
+                    self.output.send(Note(pitch=pitch, velocity=1.))
+
+
+class Sequence(Composite):
+    """One sequencer channel: Phasor -> (phase insert) -> PizzaSlicer -> PatternLookup ->
+    NoteLengthener (sequencer.py:154-243).  The phase leaves through `phaseOut` and comes back
+    through `phaseIn`, so that a micro rhythm can be patched in between."""
+
+    def __init__(self, sequencer, pattern, tempo=120, beatValue=QUARTER_NOTE,
+                 grid=SIXTEENTH_NOTE, relNoteLength=.5, absNoteLength=None):
+        super().__init__()
+        self.sequencer = sequencer
+        self.pattern = atleast_1d(pattern)
+        self.tempo, self.beatValue, self.grid = tempo, beatValue, grid
+        self.phaseIn = Relay(owner=self)
+        self.phaseOut = Relay(owner=self)
+        self.inputs = [self.phaseIn]
+        self.outputs = [MessageRelay(owner=self), self.phaseOut]
+        if absNoteLength is None:
+            absNoteLength = relNoteLength * self.duration / self.length
+        self.phasor = Phasor(frequency=1. / self.duration)
+        self.pizza = PizzaSlicer(self.length)
+        self.lookup = PatternLookup(self.pattern)
+        self.lengthener = NoteLengthener(absNoteLength)
+        self.phasor | self.phaseOut
+        self.phaseOut.connect(self.phaseIn)
+        self.phaseIn | self.pizza | self.lookup | self.lengthener | self.output
+        self.update_internal_exec_order(self.phasor, self.pizza)
+
+    @property
+    def length(self):
+        return len(self.pattern)
+
+    @property
+    def duration(self):
+        """Seconds one pass through the pattern takes."""
+        return self.length * self.grid / self.beatValue * tempo_2_period(self.tempo)
+
+    def disconnect_phase_insert(self):
+        for dst in set(self.phaseOut.outgoingConnections):
+            self.phaseOut.disconnect(dst)
+        if self.phaseIn.connected:
+            self.phaseIn.incomingConnection.disconnect(self.phaseIn)
+
+    def apply_micro_rhythm(self, microRhythm):
+        self.disconnect_phase_insert()
+        self.phaseOut | microRhythm | self.phaseIn
+        self.sequencer.update_internal_exec_order()
+
+    def reset_micro_rhythm(self):
+        self.disconnect_phase_insert()
+        self.phaseOut.connect(self.phaseIn)
+        self.sequencer.update_internal_exec_order()
+
+
+class Sequencer(Composite):
+    """Pattern sequencer: one Sequence per pattern row, each on an output of its own, or all
+    through one MessageMixer with splitOutputs=False (sequencer.py:246-301).  Further
+    arguments go to every Sequence."""
+
+    def __init__(self, pattern, *args, splitOutputs=True, **kwargs):
+        super().__init__()
+        self.pattern = atleast_2d(pattern)
+        self.splitOutputs = splitOutputs
+        self.sequences = []
+        if not splitOutputs:
+            self.msgMixer = MessageMixer(nInputs=0)
+            self.outputs = [MessageRelay(owner=self)]
+            self.msgMixer | self.output
+        for row in self.pattern:
+            self.add_new_channel(row, *args, **kwargs)
+
+    def add_new_channel(self, *args, **kwargs):
+        seq = Sequence(self, *args, **kwargs)
+        self.sequences.append(seq)
+        if self.splitOutputs:
+            relay = MessageRelay(owner=self)
+            self.outputs.append(relay)
+            seq | relay
+        else:
+            self.msgMixer.add_new_channel()
+            seq | self.msgMixer.inputs[-1]
+        self.update_internal_exec_order()
+
+    @property
+    def nChannels(self):
+        return len(self.pattern)
+
+    def apply_micro_rhythm(self, microRhythm, channel):
+        self.sequences[channel].apply_micro_rhythm(microRhythm)
+
+    def reset_micro_rhythm(self, channel):
+        self.sequences[channel].reset_micro_rhythm()
+
+
+# ---- arpeggiator (klang/arpeggiator.py) ----------------------------------------------------
+
+VALID_ORDERS = ['up', 'down', 'upDown', 'downUp', 'alternating', 'random']
+
+
+def interleave(first, second):
+    """a0 b0 a1 b1 ..., then whatever the longer one has left (arpeggiator.py:31-43)."""
+    n = min(len(first), len(second))
+    out = [item for pair in zip(first[:n], second[:n]) for item in pair]
+    return out + list(first[n:]) + list(second[n:])
+
+
+def arpeggio_index_permutation(order, length):
+    """The order in which `length` sorted notes are played (arpeggiator.py:46-80)."""
+    if order not in VALID_ORDERS:
+        raise ValueError('Invalid order %r! Either: %s.'
+                         % (order, ', '.join(map(repr, VALID_ORDERS))))
+    if length == 1:
+        return [0]
+    up = list(range(length))
+    down = up[::-1]
+    if order == 'up':
+        return up
+    if order == 'down':
+        return down
+    if order == 'upDown':
+        return up[:-1] + down[:-1]
+    if order == 'downUp':
+        return down[:-1] + up[:-1]
+    if order == 'alternating':     # lowest, highest, second lowest, second highest ...
+        half = int(math.ceil(.5 * length))
+        return interleave(up[:half], up[half:][::-1])
+    permutation = list(range(length))
+    random.shuffle(permutation)
+    return permutation
+
+
+class Arpeggio(collections.abc.Sequence):
+    """The held notes, sorted, and a cursor into the current order's permutation
+    (arpeggiator.py:83-163)."""
+
+    def __init__(self, order='up', initialNotes=None):
+        arpeggio_index_permutation(order, 1)   # validates the order
+        self.order = order
+        self.notes = []
+        self.permutation = []
+        self.current = 0
+        for note in initialNotes or ():
+            self.add_note(note)
+
+    def wrap_current(self):
+        self.current = self.current % len(self.permutation) if self.permutation else 0
+
+    def update_state(self):
+        self.permutation = arpeggio_index_permutation(self.order, len(self))
+        self.wrap_current()
+
+    def add_note(self, note):
+        if note not in self:
+            bisect.insort(self.notes, note)
+            self.update_state()
+
+    def remove_note(self, note):
+        for held in self.notes:
+            if held.pitch == note.pitch:
+                self.notes.remove(held)
+                self.update_state()
+                return
+        raise ValueError('No note with pitch %d in Arpeggio' % note.pitch)
+
+    def __getitem__(self, index):
+        return self.notes[index]
+
+    def __len__(self):
+        return len(self.notes)
+
+    def __contains__(self, note):
+        return any(held.pitch == note.pitch for held in self.notes)
+
+    def __next__(self):
+        if not self.notes:
+            raise StopIteration
+        index = self.permutation[self.current]
+        self.current += 1
+        self.wrap_current()
+        return self.notes[index]
+
+
+class Arpeggiator(Composite):
+    """Plays the held notes one after the other, one per `interval`: whenever the internal
+    phasor wraps, the previous note is silenced and the next one sent
+    (arpeggiator.py:166-194)."""
+
+    def __init__(self, interval=.1, *args, **kwargs):
+        super().__init__()
+        interval = compute_duration(interval)
+        self.inputs = [MessageInput(owner=self)]
+        self.outputs = [MessageOutput(owner=self)]
+        self.prevPhase = 0.
+        self.prevNote = None
+        self.phasor = Phasor(1. / interval)
+        self.arpeggio = Arpeggio(*args, **kwargs)
+
+    def update(self):
+        for note in self.input.receive():
+            if note.on:
+                self.arpeggio.add_note(note)
+            elif note in self.arpeggio:
+                self.arpeggio.remove_note(note)
+        self.phasor.update()
+        phase = self.phasor.output.value
+        if phase <= self.prevPhase:
+            if self.prevNote:
+                self.output.send(self.prevNote.silence())
+            if self.arpeggio:
+                self.prevNote = next(self.arpeggio)
+                self.output.send(self.prevNote)
+        self.prevPhase = phase

@@ -1,19 +1,79 @@
-"""Tempo-aware rates and durations (klang/music/tempo.py:19-108): a Fraction is a
-note value relative to TEMPO / METRE, anything else passes through."""
+"""Tempo-aware rates and durations (klang/music/tempo.py:19-108), the metre helpers they rest
+on (klang/music/metre.py:23-136) and the note values (klang/music/note_values.py:40-51): a
+Fraction is a note value relative to TEMPO / METRE, anything else passes through."""
 from fractions import Fraction
 
 from klang_amd.config import METRE, TEMPO
+from klang_amd.constants import TAU
+
+WHOLE_NOTE = Fraction(1, 1)
+HALF_NOTE = Fraction(1, 2)
+QUARTER_NOTE = Fraction(1, 4)
+EIGHT_NOTE = Fraction(1, 8)
+SIXTEENTH_NOTE = Fraction(1, 16)
+THIRTY_SECOND_NOTE = Fraction(1, 32)
+DOTTED_HALF_NOTE = Fraction(3, 4)
+DOTTED_QUARTER_NOTE = Fraction(3, 8)
+DOTTED_EIGHT_NOTE = Fraction(3, 16)
+
+
+def create_metre(numerator, denominator=None):
+    """A time signature: a Fraction that is NOT reduced, so 6/8 keeps its 8 (metre.py:23-37)."""
+    return Fraction(numerator, denominator, _normalize=False)
+
+
+FOUR_FOUR_METRE = create_metre(4, 4)
+THREE_FOUR_METRE = create_metre(3, 4)
+SIX_EIGHT_METRE = create_metre(6, 8)
+
+
+def is_compound(metre):
+    """6/8, 9/8, 12/8 ... (metre.py:80-84)."""
+    return metre.numerator >= 6 and metre.numerator % 3 == 0
+
+
+def is_complex(metre):
+    """Numerator divisible by neither 2 nor 3: 5/4, 7/8 ... (metre.py:70-77)."""
+    return metre.numerator % 2 != 0 and metre.numerator % 3 != 0
 
 
 def default_beat_value(metre):
-    """klang/music/metre.py: the beat value of a metre is 1 / denominator."""
-    return Fraction(1, metre.denominator)
+    """Best-guess beat of a metre: three denominators for a compound metre, two for a complex
+    one, else one (metre.py:96-127)."""
+    if is_compound(metre):
+        return create_metre(3, metre.denominator)
+    if is_complex(metre):
+        return create_metre(2, metre.denominator)
+    return create_metre(1, metre.denominator)
+
+
+def tempo_2_frequency(tempo):
+    """Beats per minute -> beats per second (tempo.py:19-29)."""
+    return tempo / 60.
+
+
+def tempo_2_period(tempo):
+    """Beats per minute -> seconds per beat (tempo.py:32-41)."""
+    return 1. / tempo_2_frequency(tempo)
+
+
+def bar_period(tempo, metre=METRE, beatValue=None):
+    """Seconds per bar (tempo.py:44-61)."""
+    if beatValue is None:
+        beatValue = default_beat_value(metre)
+    return metre / tempo_2_frequency(tempo) / beatValue
+
+
+def angular_velocity(tempo, metre=METRE, beatValue=None):
+    """Bar phase per second (tempo.py:64-67)."""
+    return TAU / bar_period(tempo, metre, beatValue)
 
 
 def note_duration(note, tempo=TEMPO, metre=METRE, beatValue=None):
+    """Seconds a note value lasts (tempo.py:70-90)."""
     if beatValue is None:
         beatValue = default_beat_value(metre)
-    beat_period = 1. / (tempo / 60.)
+    beat_period = 1. / tempo_2_frequency(tempo)
     return beat_period / beatValue * note
 
 

@@ -14,15 +14,19 @@ pytestmark = pytest.mark.gpu
 B = 256
 
 
-@pytest.mark.parametrize('name,duration,channels', [
-    ('hello_world', .3, 1), ('haunting_envelopes', .5, 2), ('reverberation_demo', 1.6, 1),
-    ('synthesizer_demo', 1.5, 1), ('drum_machine', 2.2, 1)])
-def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, channels):
+@pytest.mark.parametrize('name,duration,channels,kwargs', [
+    ('hello_world', .3, 1, {}), ('haunting_envelopes', .5, 2, {}),
+    ('reverberation_demo', 1.6, 1, {}), ('synthesizer_demo', 1.5, 1, {}),
+    ('drum_machine', 2.2, 1, {}),
+    ('sequencer_demo', 2.5, 1, {}),                   # Sequencer stays on the host (HiHat)
+    ('sequencer_demo', 2.5, 1, dict(hihat=False)),    # Sequencer run ahead, notes prescheduled
+    ('arpeggiator_demo', 3., 1, {})])
+def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, channels, kwargs):
     mod = importlib.import_module('examples.' + name)
     out = {}
     for backend in ('hip', 'host'):
         path = str(tmp_path / ('%s_%s.wav' % (name, backend)))
-        frames = run_klang(mod.build(), backend=backend, filepath=path, offline=True,
+        frames = run_klang(mod.build(**kwargs), backend=backend, filepath=path, offline=True,
                            duration=duration, fadeout=.1)
         with wave.open(path, 'rb') as wf:
             assert wf.getnchannels() == channels and wf.getframerate() == 44100
@@ -31,5 +35,23 @@ def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, chan
     got, want = out['hip'][0], out['host'][0]
     assert got.shape == want.shape == (int(duration * 44100 // B) * B, channels)
     assert np.abs(want).max() > .02
-    assert report('example patch: ' + name, np.abs(got - want).max()) <= 1e-5
+    label = name + (' ' + ','.join('%s=%s' % kv for kv in kwargs.items()) if kwargs else '')
+    assert report('example patch: ' + label, np.abs(got - want).max()) <= 1e-5
     assert np.abs(out['hip'][1] - out['host'][1]).max() <= 2   # int16 steps after normalisation
+
+
+def test_sequencer_is_run_ahead_for_an_offline_bounce(hip):
+    """With every note going to device blocks the Sequencer leaves the order (its notes are
+    queued on the device for the whole piece); with a host HiHat listening it stays."""
+    from examples import sequencer_demo
+    from klang_amd import fusion
+    from klang_amd.klang import preschedule
+    from klang_amd.schedule import determine_execution_order
+    from klang_amd.sequencing import Sequencer
+    for hihat, stays in ((False, False), (True, True)):
+        order = determine_execution_order([sequencer_demo.build(hihat=hihat)])
+        order, banks = fusion.compile_order(order, strict=True)
+        order = preschedule(order, banks, 300)
+        assert any(isinstance(b, Sequencer) for b in order) == stays
+        for bank in banks:
+            bank.close()

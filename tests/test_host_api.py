@@ -167,7 +167,8 @@ def test_composite_and_unpatch():
 
 # ---- voice / note (tests/test_audio_voices.py) -----------------------------------------------
 def test_note_validation():
-    assert Note(69).frequency == 440. and Note(69).on and Note(69, 0.).off
+    # the reference's Temperament arithmetic (tunings.py:56-69) gives 440 Hz minus one ulp
+    assert Note(69).frequency == 439.99999999999994 and Note(69).on and Note(69, 0.).off
     for bad in (dict(pitch=-1), dict(pitch=128), dict(pitch=60, velocity=1.5),
                 dict(pitch=60, frequency=-1.)):
         with pytest.raises(ValueError):
@@ -525,3 +526,21 @@ def test_voice_known_answers():
     osc, lfo, env = PwmOscillator(), Oscillator(), ADSR()
     lfo.output.connect(osc.dutyCycle)
     assert Voice(osc, env).execOrder == [env, lfo, osc]
+
+
+def test_temperament_known_answers(golden):
+    """tests/test_music_tunings.py restated, and the default Note frequencies bit for bit as
+    the reference's notes carry them (fixture rows written from real Note objects)."""
+    from klang_amd.tunings import CENT_PER_OCTAVE, Temperament, cent_2_ratio, ratio_2_cent
+    assert ratio_2_cent(2.) == CENT_PER_OCTAVE and cent_2_ratio(CENT_PER_OCTAVE) == 2.
+    for kammerton in (440., 435.23):
+        equal = Temperament(np.arange(12) * 100, kammerton=kammerton)
+        for i in range(-6, 6):
+            assert abs(equal.pitch_2_frequency(69 + 12 * i) - kammerton * 2. ** i) < 1e-7
+    seen = {}
+    for rows in (golden('sequencing')[k] for k in ('split', 'merged', 'quarter', 'arp_up')):
+        seen.update({int(r[2]): r[4] for r in rows})
+    assert len(seen) >= 12
+    for pitch, frequency in seen.items():
+        assert Note(pitch).frequency == frequency
+    assert Note(60, temperament=Temperament(np.arange(12) * 100, kammerton=432.)).frequency < 260.

@@ -663,6 +663,52 @@ def main():
         bo[name + '_params'] = np.array([duration, fadeout])
     save('bounce', **bo)
 
+    # ---- note sources: sequencer.py, arpeggiator.py, note_effects.py ----
+    # run under the engine's clock (klanggeber.py:232, 249: a running sum of INTERVAL); every
+    # note that leaves is a row [buffer, channel, pitch, velocity, frequency]
+    from klang.arpeggiator import Arpeggiator
+    from klang.clock import ClockMixin
+    from klang.connections import MessageInput
+    from klang.sequencer import Sequencer
+    from klang.audio.helpers import INTERVAL
+    from fractions import Fraction
+
+    def run_source(block, n_buffers, feed=None):
+        sinks = []
+        for out in block.outputs:
+            sink = MessageInput()
+            out.connect(sink)
+            sinks.append(sink)
+        rows, play_time = [], 0.
+        for k in range(n_buffers):
+            ClockMixin.set_current_time(play_time)
+            for note in (feed or {}).get(k, ()):
+                block.input.push(note)
+            block.update()
+            for ch, sink in enumerate(sinks):
+                for note in sink.receive():
+                    rows.append([k, ch, note.pitch, note.velocity, note.frequency])
+            play_time += INTERVAL
+        ClockMixin.set_current_time(0.)
+        return np.array(rows, dtype=float).reshape(-1, 5)
+
+    sq = {}
+    sq['split'] = run_source(Sequencer([[60, 0, 63, 67, [60, 64], 0, 72, 65], [36, 0, 0, 43]],
+                                       tempo=125), 700)
+    sq['merged'] = run_source(Sequencer([[48, 55, 0, 51], [72, 0, 70, 0, 67, 0]], tempo=97,
+                                        grid=Fraction(1, 8), absNoteLength=.21,
+                                        splitOutputs=False), 700)
+    sq['quarter'] = run_source(Sequencer([60, 62, 64, 65], tempo=120, grid=Fraction(1, 4),
+                                         relNoteLength=.9), 700)
+    chord = {3: [E(60, .8), E(67, .7), E(64, .9)], 150: [E(72, .6)], 260: [E(64, 0.)],
+             400: [E(60, 0.), E(67, 0.), E(72, 0.), E(50, 0.)], 480: [E(55, .5)]}
+    for order in ('up', 'down', 'upDown', 'downUp', 'alternating'):
+        sq['arp_' + order] = run_source(Arpeggiator(.11, order), 600, chord)
+    sq['arp_note_value'] = run_source(Arpeggiator(Fraction(1, 16), 'up'), 300, chord)
+    sq['arp_feed'] = np.array([[k, n.pitch, n.velocity] for k, ns in sorted(chord.items())
+                               for n in ns])
+    save('sequencing', **sq)
+
     # ---- hello_world (config 1): Oscillator(440) | Dac, pre-normalisation ---
     osc = OSC.Oscillator(frequency=440.)
     blocks = []
