@@ -5,8 +5,9 @@ from klang_amd.audio.signals import (Chirper, FmOscillator, Lfo, Oscillator, Pha
 from klang_amd.audio.envelopes import ADSR, AR, D, R, Envelope
 from klang_amd.audio.filtering import (BackwardCombFilter, EchoFilter, Filter,
                                        ForwardCombFilter, Reverb)
-from klang_amd.audio.effects import (Bitcrusher, Delay, Gain, OctaveDistortion, RingModulator,
-                                     Subsampler, TanhDistortion, Transformer, Tremolo)
+from klang_amd.audio.effects import (AudioCombiner, AudioSplitter, Bitcrusher, Delay, Gain,
+                                     OctaveDistortion, RingModulator, StereoDelay, Subsampler,
+                                     TanhDistortion, Transformer, Tremolo)
 from klang_amd.audio.mixers import Mixer, StereoMixer
 from klang_amd.audio.voices import Voice
 from klang_amd.audio.synthesizer import (HiHat, Kick, MonophonicSynthesizer, NoteScheduler,
@@ -17,5 +18,5 @@ __all__ = ['Chirper', 'FmOscillator', 'Lfo', 'Oscillator', 'Phasor', 'PwmOscilla
            'sawtooth', 'sine', 'square', 'triangle', 'ADSR', 'AR', 'D', 'R', 'Envelope',
            'BackwardCombFilter', 'EchoFilter', 'Filter', 'ForwardCombFilter', 'Reverb', 'Mixer',
            'StereoMixer', 'Voice', 'HiHat', 'Kick', 'MonophonicSynthesizer', 'NoteScheduler', 'PolyphonicSynthesizer',
-           'Synthesizer', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
+           'Synthesizer', 'AudioCombiner', 'AudioSplitter', 'StereoDelay', 'Delay', 'Gain', 'OctaveDistortion', 'TanhDistortion',
            'Transformer', 'Tremolo', 'Bitcrusher', 'RingModulator', 'Subsampler', 'Adc', 'Dac', 'run_audio_engine', 'write_wave']

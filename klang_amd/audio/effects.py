@@ -1,8 +1,8 @@
 """Element-wise and delay effects (host side): ``Gain``, ``Transformer``,
-``TanhDistortion``, ``OctaveDistortion``, ``Tremolo``, ``Delay``, ``Subsampler``,
-``Bitcrusher``, ``RingModulator``.
+``TanhDistortion``, ``OctaveDistortion``, ``Tremolo``, ``Delay``, ``StereoDelay`` (with
+``AudioSplitter`` / ``AudioCombiner``), ``Subsampler``, ``Bitcrusher``, ``RingModulator``.
 
-Mirrors klang/audio/effects.py:33-174, 388-449, 452-561, 618-662 and
+Mirrors klang/audio/effects.py:33-236, 388-449, 452-561, 618-662 and
 klang/ring_buffer.py:10-113.
 The ``update()`` methods are the ``backend='host'`` evaluation; inside a fused
 voice chain the same stages run on the device (mod_kernels.h).
@@ -19,12 +19,12 @@ from klang_amd.block import Block
 from klang_amd.composite import Composite
 from klang_amd.config import BUFFER_SIZE, SAMPLING_RATE
 from klang_amd.ring_buffer import RingBuffer
-from klang_amd.constants import MONO
+from klang_amd.constants import MONO, STEREO
 from klang_amd.tempo import compute_duration
 from klang_amd.wiring import Input, Relay
 
 __all__ = ['Gain', 'Transformer', 'TanhDistortion', 'OctaveDistortion', 'Tremolo', 'Delay',
-           'DelayLine', 'Subsampler', 'Bitcrusher', 'RingModulator', 'low_pass_coefficients']
+           'DelayLine', 'AudioSplitter', 'AudioCombiner', 'StereoDelay', 'Subsampler', 'Bitcrusher', 'RingModulator', 'low_pass_coefficients']
 
 
 @functools.lru_cache()
@@ -160,6 +160,56 @@ class Delay(Block):
         old = self.ring.peek()
         self.ring.extend(new + self.feedback * old)
         self.output.set_value(blend(new, old, self.drywet))
+
+
+class AudioSplitter(Block):
+    """One multi-channel input -> one mono output per channel; a mono input goes to every
+    output as it is (effects.py:177-192)."""
+
+    def __init__(self, nOutputs):
+        super().__init__(nInputs=1, nOutputs=nOutputs)
+
+    def update(self):
+        samples = self.input.value
+        if np.ndim(samples) == MONO:
+            for output in self.outputs:
+                output.set_value(samples)
+        else:
+            for channel, output in zip(samples, self.outputs):
+                output.set_value(channel)
+
+
+class AudioCombiner(Block):
+    """Mono inputs -> the rows of one multi-channel output, written in place
+    (effects.py:195-207)."""
+
+    def __init__(self, nInputs):
+        super().__init__(nInputs, nOutputs=1)
+        self.output.set_value(np.zeros((nInputs, BUFFER_SIZE)))
+
+    def update(self):
+        for input_, row in zip(self.inputs, self.output.value):
+            row[:] = input_.value
+
+
+class StereoDelay(Composite):
+    """Two Delays, one per channel, between a splitter and a combiner (effects.py:210-236).
+    Under backend='hip' the graph compiler opens the composite up and each Delay becomes a
+    device chain fed from its splitter output."""
+
+    def __init__(self, leftTime=1., rightTime=1., leftFeedback=.1, rightFeedback=.1, drywet=.5):
+        super().__init__()
+        self.inputs = [Relay(owner=self)]
+        self.outputs = [Relay(owner=self)]
+        splitter = AudioSplitter(nOutputs=STEREO)
+        self.leftDelay = Delay(leftTime, leftFeedback, drywet)
+        self.rightDelay = Delay(rightTime, rightFeedback, drywet)
+        combiner = AudioCombiner(nInputs=STEREO)
+        self.input.connect(splitter.input)
+        splitter.outputs[0] | self.leftDelay | combiner.inputs[0]
+        splitter.outputs[1] | self.rightDelay | combiner.inputs[1]
+        combiner.output.connect(self.output)
+        self.update_internal_exec_order()
 
 
 class Subsampler(Block):

@@ -458,6 +458,8 @@ class GpuVoiceBank(Block):
         rows = []
         for c in self.chains:
             value = np.asarray(c.external.value, dtype=np.float64)
+            if value.ndim == 2 and c.stages and type(c.stages[0]) is Delay:
+                value = value.sum(axis=0) / value.shape[0]   # Delay's down-mix (effects.py:166-168)
             if value.shape != (BUFFER_SIZE,):
                 raise KlangError('%s: the device chain takes mono buffers of %d samples, got shape '
                                  '%s from %s' % (self, BUFFER_SIZE, value.shape, c.external.owner))
@@ -660,6 +662,23 @@ def _flat(order):
             yield from _flat(blk.execOrder)
 
 
+def open_composites(order):
+    """Composites that merely run their inner blocks (Composite.update as it is: StereoDelay)
+    and hold hot-path blocks are replaced by those inner blocks, in their inner order: relays
+    pass values through, so the flat order computes the same thing and the inner blocks
+    become visible to the chain search.  Composites with an update of their own (Voice,
+    Tremolo, RingModulator) are device stages as a whole and stay closed."""
+    flat = []
+    for blk in order:
+        if (isinstance(blk, Composite) and type(blk).update is Composite.update
+                and any(isinstance(b, HOT_PATH_TYPES) and type(b) not in (Phasor, Lfo)
+                        for b in _flat(blk.execOrder))):
+            flat.extend(open_composites(blk.execOrder))
+        else:
+            flat.append(blk)
+    return flat
+
+
 def find_fusable(exec_order):
     """-> (groups, errors): groups = [(sink, [Chain, ...], synthesizers)] for every mixer whose
     inputs are uniform chains and for every other chain end; errors = reasons
@@ -728,6 +747,7 @@ def find_fusable(exec_order):
 def compile_order(exec_order, ctx=None, strict=True):
     """Replace fusable chains in `exec_order` by GpuVoiceBank blocks.  With
     strict=True every hot-path block must end up fused (KlangError otherwise)."""
+    exec_order = open_composites(exec_order)
     groups, errors = find_fusable(exec_order)
     fused_blocks, banks_at = set(), {}
     for sink, chains, synths in groups:

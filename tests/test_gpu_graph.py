@@ -12,6 +12,7 @@ from klang_amd.errors import KlangError
 from klang_amd.klang import run_klang
 from klang_amd.messages import Note
 from klang_amd.schedule import determine_execution_order
+from tests.helpers import report
 
 pytestmark = pytest.mark.gpu
 B = 256
@@ -293,6 +294,39 @@ def test_host_side_gain_edits_reach_the_device(hip):
         out.append(np.array(gain.output.value))
     banks[0].close()
     assert abs(np.abs(out[2]).max() - 1.) < 1e-2 and abs(np.abs(out[4]).max() - .25) < 1e-2
+
+
+@pytest.mark.parametrize('stereo,key', [(True, 'stereo_delay'), (False, 'stereo_delay_mono_in')])
+def test_stereo_delay_is_opened_and_its_delays_run_on_the_device(hip, golden, stereo, key):
+    """StereoDelay (effects.py:210-236) is a Composite of splitter, two Delays and combiner:
+    the compiler opens it, each Delay becomes a device chain fed from its splitter output, and
+    the stereo frames equal what the real reference's StereoDelay produced."""
+    from klang_amd.audio import AudioCombiner, StereoDelay
+
+    def build():
+        left, right = Oscillator(frequency=220., wave_func=sawtooth), Oscillator(311.)
+        sd = StereoDelay(leftTime=.05, rightTime=.08, leftFeedback=.5, rightFeedback=.3, drywet=.4)
+        if stereo:
+            comb = AudioCombiner(nInputs=2)
+            left | comb.inputs[0]
+            right | comb.inputs[1]
+            comb | sd
+        else:
+            left | sd
+        return sd | Dac(nChannels=2)
+
+    order, banks = fusion.compile_order(determine_execution_order([build()]))
+    names = [type(b).__name__ for b in order]
+    assert 'StereoDelay' not in names and 'Delay' not in names
+    assert names[-5:] == ['AudioSplitter', 'GpuVoiceBank', 'GpuVoiceBank', 'AudioCombiner', 'Dac']
+    for bank in banks:
+        bank.close()
+    want = golden('effects')[key]                       # [blocks][2][256]
+    dur = len(want) * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0.))
+    want = want.transpose(0, 2, 1).reshape(-1, 2)
+    assert got.shape == want.shape
+    assert report('StereoDelay (two device delay lines)', np.abs(got - want).max()) <= 1e-5
 
 
 # ---- synthesizers (SURVEY 8f rank 3) -------------------------------------------------------

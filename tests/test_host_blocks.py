@@ -475,3 +475,32 @@ def test_host_hihat_vs_golden_with_the_same_seed(golden):
     finally:
         np.random.set_state(state)
     assert HiHat not in fusion.HOT_PATH_TYPES
+
+
+def _stereo_delay_patch(stereo):
+    from klang_amd.audio import AudioCombiner, StereoDelay
+    left, right = Oscillator(frequency=220., wave_func=sawtooth), Oscillator(311.)
+    sd = StereoDelay(leftTime=.05, rightTime=.08, leftFeedback=.5, rightFeedback=.3, drywet=.4)
+    if stereo:
+        comb = AudioCombiner(nInputs=2)
+        left | comb.inputs[0]
+        right | comb.inputs[1]
+        comb | sd
+    else:
+        left | sd
+    return sd
+
+
+@pytest.mark.parametrize('stereo,key', [(True, 'stereo_delay'), (False, 'stereo_delay_mono_in')])
+def test_host_stereo_delay_vs_golden(golden, stereo, key):
+    """StereoDelay = AudioSplitter -> two Delays -> AudioCombiner (effects.py:177-236): the
+    host composite bit for bit, on a stereo signal and on a mono one."""
+    sd = _stereo_delay_patch(stereo)
+    assert [type(b).__name__ for b in sd.execOrder] == ['AudioSplitter', 'Delay', 'Delay',
+                                                        'AudioCombiner']
+    order = determine_execution_order([sd])
+    want = golden('effects')[key]
+    for b in range(len(want)):
+        for blk in order:
+            blk.update()
+        np.testing.assert_array_equal(sd.output.value, want[b])

@@ -531,6 +531,29 @@ def main():
              10: [lambda: voice.input.push(Note(57, 0., frequency=220.))],
              14: [lambda: voice.input.push(Note(64, .5, frequency=329.6275569128699))]}
     fx['chain'] = run_graph(stages[-1], 30, hooks)
+
+    # StereoDelay (effects.py:210-236) on a stereo signal (two oscillators into an
+    # AudioCombiner) and on a mono one (the splitter hands it to both delays)
+    def stereo_delay_run(stereo):
+        left, right = OSC.Oscillator(frequency=220., wave_func=W.sawtooth), OSC.Oscillator(311.)
+        sd = FX.StereoDelay(leftTime=.05, rightTime=.08, leftFeedback=.5, rightFeedback=.3,
+                            drywet=.4)
+        if stereo:
+            comb = FX.AudioCombiner(nInputs=2)
+            left | comb.inputs[0]
+            right | comb.inputs[1]
+            comb | sd
+        else:
+            left | sd
+        order = determine_execution_order([sd])
+        outs = []
+        for b in range(40):
+            for o in order:
+                o.update()
+            outs.append(np.array(sd.output.value, dtype=float))
+        return np.array(outs)
+    fx['stereo_delay'] = stereo_delay_run(True)
+    fx['stereo_delay_mono_in'] = stereo_delay_run(False)
     save('effects', **fx)
 
     # ---- synthesizers: synthesizer.py:87-219 -----------------
