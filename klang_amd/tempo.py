@@ -6,15 +6,22 @@ from fractions import Fraction
 from klang_amd.config import METRE, TEMPO
 from klang_amd.constants import TAU
 
-WHOLE_NOTE = Fraction(1, 1)
-HALF_NOTE = Fraction(1, 2)
-QUARTER_NOTE = Fraction(1, 4)
-EIGHT_NOTE = Fraction(1, 8)
-SIXTEENTH_NOTE = Fraction(1, 16)
-THIRTY_SECOND_NOTE = Fraction(1, 32)
-DOTTED_HALF_NOTE = Fraction(3, 4)
-DOTTED_QUARTER_NOTE = Fraction(3, 8)
-DOTTED_EIGHT_NOTE = Fraction(3, 16)
+# note_values.py:40-90: LARGE_NOTE (8 whole notes) ... TWO_HUNDRED_FIFTY_SIXTH_NOTE, each also
+# DOTTED_ (x 3/2), DOUBLE_DOTTED_ (x 7/4) and TRIPLE_DOTTED_ (x 15/8)
+_NAMES = ('LARGE', 'LONG', 'DOUBLE_WHOLE', 'WHOLE', 'HALF', 'QUARTER', 'EIGHT', 'SIXTEENTH',
+          'THIRTY_SECOND', 'SIXTY_FOURTH', 'HUNDRED_TWENTY', 'TWO_HUNDRED_FIFTY_SIXTH')
+NOTE_VALUES = {}
+for _k, _name in enumerate(_NAMES):
+    _base = Fraction(8, 1) / 2 ** _k
+    for _prefix, _factor in (('', Fraction(1)), ('DOTTED_', Fraction(3, 2)),
+                             ('DOUBLE_DOTTED_', Fraction(7, 4)), ('TRIPLE_DOTTED_', Fraction(15, 8))):
+        NOTE_VALUES['%s%s_NOTE' % (_prefix, _name)] = _base * _factor
+globals().update(NOTE_VALUES)
+
+
+def dot_note(note, n=1):
+    """A note value with n dots: note * (2 - 1 / 2**n) (note_values.py:93-101)."""
+    return note * (2 - Fraction(1, 2 ** n))
 
 
 def create_metre(numerator, denominator=None):

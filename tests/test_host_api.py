@@ -428,6 +428,27 @@ def test_note_durations():
     assert compute_duration(.3) == .3 and compute_rate(5.) == 5.
 
 
+def test_bar_periods_and_note_values():
+    """tests/test_tempo.py:13-18 (bar_period with simple, waltz and compound metres) and the
+    note-value table (note_values.py:40-90)."""
+    from fractions import Fraction
+    from klang_amd import tempo
+    assert tempo.bar_period(120) == 2.0 and tempo.bar_period(100) == 2.4
+    assert tempo.bar_period(120, tempo.create_metre(3, 4)) == 1.5
+    assert tempo.bar_period(80, tempo.create_metre(6, 8)) == 1.5
+    beat = tempo.default_beat_value(tempo.create_metre(7, 8))       # un-reduced 2/8
+    assert (beat.numerator, beat.denominator) == (2, 8)
+    assert tempo.create_metre(6, 8).denominator == 8            # not reduced
+    assert tempo.note_duration(tempo.EIGHT_NOTE, 120, tempo.FOUR_FOUR_METRE) == .25
+    assert (tempo.LARGE_NOTE, tempo.DOTTED_LARGE_NOTE, tempo.DOUBLE_DOTTED_QUARTER_NOTE,
+            tempo.TRIPLE_DOTTED_TWO_HUNDRED_FIFTY_SIXTH_NOTE) == (8, 12, Fraction(7, 16),
+                                                                 Fraction(15, 2048))
+    assert len(tempo.NOTE_VALUES) == 48
+    assert tempo.dot_note(tempo.QUARTER_NOTE) == tempo.DOTTED_QUARTER_NOTE
+    assert tempo.dot_note(tempo.HALF_NOTE, 3) == tempo.TRIPLE_DOTTED_HALF_NOTE
+    assert tempo.tempo_2_period(120) == .5 and tempo.tempo_2_frequency(90) == 1.5
+
+
 def test_find_next_primes():
     """tests/test_primes.py:8-54: the primes under 100, from any start."""
     from klang_amd.audio.filtering import find_next_primes
