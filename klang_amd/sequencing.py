@@ -18,6 +18,7 @@ import random
 
 import numpy as np
 
+from klang_amd.audio.filtering import blend
 from klang_amd.audio.signals import Phasor
 from klang_amd.block import Block
 from klang_amd.clock import ClockMixin
@@ -27,7 +28,8 @@ from klang_amd.messages import Note
 from klang_amd.tempo import QUARTER_NOTE, SIXTEENTH_NOTE, compute_duration, tempo_2_period
 from klang_amd.wiring import MessageInput, MessageOutput, MessageRelay, Relay
 
-__all__ = ['NoteLengthener', 'MaxNotes', 'MessageMixer', 'random_pattern', 'pizza_slice_number',
+__all__ = ['NoteLengthener', 'MaxNotes', 'MessageMixer', 'euclidian_rhythm', 'MicroRhyhtm',
+           'random_pattern', 'pizza_slice_number',
            'atleast_1d', 'atleast_2d', 'PizzaSlicer', 'PatternLookup', 'Sequence', 'Sequencer',
            'VALID_ORDERS', 'interleave', 'arpeggio_index_permutation', 'Arpeggio',
            'Arpeggiator']
@@ -102,6 +104,69 @@ class MessageMixer(Block):
         for inp in self.inputs:
             for message in inp.receive():
                 self.output.send(message)
+
+
+# ---- rhythm (klang/music/rhythm.py) ----------------------------------------------------------
+
+def euclidian_rhythm(nPulses, nSlots):
+    """nPulses spread as evenly as possible over nSlots, as a 0/1 list (Bjorklund's algorithm
+    as rhythm.py:28-81 runs it: counts and remainders of a Euclid-style division, the string
+    built recursively from them, then reversed)."""
+    divisor = nSlots - nPulses
+    remainder, count, level = [nPulses], [], 0
+    while remainder[level] > 1:
+        count.append(divisor // remainder[level])
+        remainder.append(divisor % remainder[level])
+        divisor = remainder[level]
+        level += 1
+    count.append(divisor)
+    bitmap = []
+
+    def build(lvl):
+        if lvl == -1:
+            bitmap.append(0)
+        elif lvl == -2:
+            bitmap.append(1)
+        else:
+            for _ in range(count[lvl]):
+                build(lvl - 1)
+            if remainder[lvl]:
+                build(lvl - 2)
+
+    build(level)
+    return bitmap[::-1]
+
+
+class MicroRhyhtm(Block):
+    """(Spelt as in the reference.)  Warps a bar phase so that evenly spaced steps land on an
+    uneven note pattern: the pattern's note starts, as angles, are mapped onto equal angles by
+    interpolation; `phrasing` (a value input) blends between the straight and the warped
+    phase (rhythm.py:103-172).  Patched into a Sequence's phase insert."""
+
+    def __init__(self, notes, phrasing=1., beatValue=QUARTER_NOTE, kind='linear', name=''):
+        super().__init__(nInputs=2, nOutputs=1, name=name)
+        self.notes = notes
+        self.beatValue = beatValue
+        self.phrasing = self.inputs[1]
+        self.phrasing.set_value(phrasing)
+        self.interpolator = self.create_phase_interpolator(notes, kind)
+
+    @staticmethod
+    def create_phase_interpolator(notes, kind):
+        import scipy.interpolate
+        duration = sum(notes)
+        starts = list(itertools.accumulate(notes[:-1], initial=type(duration)()))
+        angles = (TAU / duration * np.r_[starts, duration]).astype(float)
+        return scipy.interpolate.interp1d(angles, np.linspace(0, TAU, len(notes) + 1), kind)
+
+    def warp(self, phase, n=None):
+        """`n`: how many times the pattern repeats on the circle (default: beats per whole note)."""
+        n = n or 1 // self.beatValue
+        groove = (self.interpolator(n * phase % TAU) + int(n * phase / TAU) * TAU) / n
+        return blend(phase % TAU, groove, self.phrasing.value)
+
+    def update(self):
+        self.output.set_value(self.warp(self.input.value))
 
 
 # ---- sequencer (klang/sequencer.py) --------------------------------------------------------

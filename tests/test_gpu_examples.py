@@ -21,7 +21,8 @@ B = 256
     ('sequencer_demo', 2.5, 1, {}),                   # Sequencer stays on the host (HiHat)
     ('sequencer_demo', 2.5, 1, dict(hihat=False)),    # Sequencer run ahead, notes prescheduled
     ('arpeggiator_demo', 3., 1, {}),
-    ('tempo_aware_effects', 2.5, 2, {})])        # note-value rates and times, StereoDelay opened
+    ('tempo_aware_effects', 2.5, 2, {}),
+    ('micro_rhythm_demo', 3., 1, dict(rate=.5))])        # note-value rates and times, StereoDelay opened
 def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, channels, kwargs):
     mod = importlib.import_module('examples.' + name)
     out = {}

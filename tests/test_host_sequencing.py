@@ -340,3 +340,35 @@ def test_preschedule_leaves_open_source_sets_alone():
     assert preschedule(order, [bank], 100) == order and bank.rows == []
     assert seq.sequences[0].pizza.currentIdx == -1
     assert preschedule(order, [bank], None) == order      # no known length: nothing to run ahead
+
+
+# ---- micro rhythm (klang/music/rhythm.py) --------------------------------------------------------
+
+def test_micro_rhythm_warp_and_euclidian_patterns_vs_reference(golden):
+    from klang_amd.sequencing import MicroRhyhtm, euclidian_rhythm
+    g = golden('sequencing')
+    notes = [Fraction(1, 8), Fraction(1, 16), Fraction(3, 16)]
+    for row, phrasing in zip(g['micro_warp_out'], (1., .35)):
+        mr = MicroRhyhtm(notes, phrasing=phrasing)
+        got = np.array([mr.warp(x) for x in g['micro_warp_in']])
+        np.testing.assert_array_equal(got, row)
+    for row in g['euclid']:
+        pulses, slots = int(row[0]), int(row[1])
+        assert euclidian_rhythm(pulses, slots) == [int(x) for x in row[2:2 + slots]]
+    assert sum(euclidian_rhythm(5, 13)) == 5
+
+
+def test_sequencer_with_a_micro_rhythm_vs_reference(golden):
+    """examples/micro_rhythm_demo.py in small: the second row's phase goes through a
+    MicroRhyhtm whose phrasing an Lfo moves; the Lfo has to end up in the sequencer's own
+    execution order, and every note leaves in the buffer the real Sequencer sent it."""
+    from klang_amd.audio import Lfo, triangle
+    from klang_amd.sequencing import MicroRhyhtm
+    seq = Sequencer([[60, 0, 0, 0, 60, 0, 0, 0, 60, 0, 0, 0, 60, 0, 0, 60], 4 * [60, 61, 62, 63]],
+                    tempo=80)
+    lfo = Lfo(frequency=.6, wave_func=triangle)
+    mr = MicroRhyhtm([Fraction(1, 8), Fraction(1, 16), Fraction(1, 16), Fraction(1, 8)])
+    lfo | mr.phrasing
+    seq.apply_micro_rhythm(mr, channel=1)
+    assert lfo in seq.execOrder and mr in seq.execOrder
+    np.testing.assert_array_equal(run_source(seq, 900), golden('sequencing')['micro_rhythm'])

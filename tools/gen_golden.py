@@ -728,6 +728,22 @@ def main():
     for order in ('up', 'down', 'upDown', 'downUp', 'alternating'):
         sq['arp_' + order] = run_source(Arpeggiator(.11, order), 600, chord)
     sq['arp_note_value'] = run_source(Arpeggiator(Fraction(1, 16), 'up'), 300, chord)
+    # micro rhythm (music/rhythm.py, examples/micro_rhythm_demo.py): the second row's phase is
+    # warped, an Lfo inside the sequencer's order moves the phrasing
+    from klang.music.rhythm import MicroRhyhtm, euclidian_rhythm
+    mseq = Sequencer([[60, 0, 0, 0, 60, 0, 0, 0, 60, 0, 0, 0, 60, 0, 0, 60], 4 * [60, 61, 62, 63]],
+                     tempo=80)
+    mlfo = OSC.Lfo(frequency=.6, wave_func=W.triangle)
+    mr = MicroRhyhtm([Fraction(1, 8), Fraction(1, 16), Fraction(1, 16), Fraction(1, 8)])
+    mlfo | mr.phrasing
+    mseq.apply_micro_rhythm(mr, channel=1)
+    sq['micro_rhythm'] = run_source(mseq, 900)
+    sq['micro_warp_in'] = np.linspace(0., 2.5 * 6.283185307179586, 97)
+    sq['micro_warp_out'] = np.array([[MicroRhyhtm([Fraction(1, 8), Fraction(1, 16), Fraction(3, 16)],
+                                                  phrasing=ph).warp(x) for x in sq['micro_warp_in']]
+                                     for ph in (1., .35)])
+    sq['euclid'] = np.array([[p, n] + euclidian_rhythm(p, n) + [-1] * (16 - n)
+                             for p, n in ((3, 8), (5, 8), (2, 5), (7, 16), (4, 12), (5, 13), (1, 4))])
     sq['arp_feed'] = np.array([[k, n.pitch, n.velocity] for k, ns in sorted(chord.items())
                                for n in ns])
     save('sequencing', **sq)
