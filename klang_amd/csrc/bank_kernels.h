@@ -231,7 +231,10 @@ __device__ __forceinline__ void lfo_cutoff_step(const BankView &bk, int v, doubl
 // grid.x = ceil(count / 256) workgroups of 4 waves.
 // partial: [gridDim.x * 4 waves][n_blocks*planes*256] float32 (mix modes)
 // out:     voices / bus buffer (other modes)
-template <bool ENV, bool FILT, int MODE>
+// GATED (synthesizer banks, synthesizer.py:151-219): a voice is only updated in a buffer in
+// which it is active or receives a note; polyphonic banks route their instrument's notes here
+// (round robin), exactly as voice_mod_kernel does for the chains this kernel does not cover.
+template <bool ENV, bool FILT, int MODE, bool GATED = false>
 __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, int count,
                                                        int block_base,      // first block, relative to this call
                                                        uint32_t clock_base,  // absolute number of block_base (events)
@@ -316,8 +319,25 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     const uint32_t ev_end = bk.ev_offset[v + 1];
     uint32_t next_ev = (live && ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
 
+    // polyphonic banks: the voice's place in its instrument and the instrument's notes
+    const int poly = GATED ? bk.poly : 0;
+    int slot = 0, rr = 0, cur_pitch = 0;
+    uint32_t nt_i = 0, nt_end = 0, next_nt = 0xFFFFFFFFu;
+    if (GATED && poly > 0) {
+        const int inst = v / poly;
+        slot = v - inst * poly;
+        rr = (int)bk.round_robin[v];
+        cur_pitch = bk.current_pitch[v];
+        nt_i = bk.nt_offset[inst] + bk.nt_cursor[v];
+        nt_end = bk.nt_offset[inst + 1];
+        next_nt = (live && nt_i < nt_end) ? bk.nt_block[nt_i] : 0xFFFFFFFFu;
+    }
+
     for (int b = 0; b < n_blocks; ++b) {
         const uint32_t abs_block = clock_base + (uint32_t)b;
+        // Voice.active (voices.py:45-53) is asked before the notes are processed
+        const bool was_active = !ENV || es.stage != 0;
+        bool had_note = false;
         // voices.py:55-64: notes are consumed at the block boundary
         while (next_ev <= abs_block) {
             const uint32_t kind = bk.ev_kind[ev_i];
@@ -326,9 +346,11 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                     es.gate(ep, true);
                 amp = bk.ev_velocity[ev_i];
                 freq = bk.ev_frequency[ev_i];
+                had_note = true;
             } else if (kind == 0u) {
                 if (ENV)
                     es.gate(ep, false);
+                had_note = true;
             } else if (kind == 2u) {
                 if (FILT) {
                     coef_row = bk.ev_index[ev_i];
@@ -340,6 +362,47 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             }
             ++ev_i;
             next_ev = (ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
+        }
+        if (GATED && poly > 0) {
+            // PolyphonicSynthesizer.process_note (synthesizer.py:200-209): every voice reads
+            // its instrument's notes of this buffer and picks out its own; note-offs match the
+            // pitch the voice's LAST update left (see voice_mod_kernel)
+            const int start_pitch = cur_pitch;
+            while (next_nt <= abs_block) {
+                const double velocity = bk.nt_velocity[nt_i];
+                const int pitch = bk.nt_pitch[nt_i];
+                if (velocity > 0.) {
+                    if (rr == slot) {
+                        if (ENV)
+                            es.gate(ep, true);
+                        amp = velocity;
+                        freq = bk.nt_frequency[nt_i];
+                        cur_pitch = pitch;
+                        had_note = true;
+                    }
+                    rr = rr + 1 == poly ? 0 : rr + 1;
+                } else if (start_pitch == pitch) {
+                    if (ENV)
+                        es.gate(ep, false);
+                    cur_pitch = 0;
+                    had_note = true;
+                }
+                ++nt_i;
+                next_nt = (nt_i < nt_end) ? bk.nt_block[nt_i] : 0xFFFFFFFFu;
+            }
+        }
+        // synthesizer.py:177-179, 214-217: an idle voice is not updated: its envelope is OFF
+        // (samples exactly 0, state unchanged) and its oscillator stays where it is
+        const bool run = !GATED || had_note || was_active;
+        if (GATED && !__any(run)) {
+            // nobody in this wavefront sounds: a buffer of zeros, no arithmetic
+            for (int c = 0; c < NCHUNK; ++c) {
+                const int s0 = b * kBlock + c * CH;
+                for (int i = 0; i < CH; ++i)
+                    emit_sample<MODE, false>(tile, i, lane, 0., gl, gr, live, out, s0, count, local);
+                flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
+            }
+            continue;
         }
 
         if (cutoff_lfo)
@@ -495,6 +558,8 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
         // oscillators.py:66-67: next start phase is sample 256 of this block
         if (wave_id != W_EXTERNAL && wave_id != W_ONE)
             phase = np_mod_tau(omega * c_time[kBlock] + start);
+        if (GATED && !run)
+            phase = start;
     }
 
     // ---- store state ----------------------------------------------------------------
@@ -514,6 +579,11 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                 bk.lfo_phase[v] = lfo_ph;
         }
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
+        if (GATED && poly > 0) {
+            bk.nt_cursor[v] = nt_i - bk.nt_offset[v / poly];
+            bk.round_robin[v] = (uint32_t)rr;
+            bk.current_pitch[v] = cur_pitch;
+        }
     }
 }
 

@@ -1320,11 +1320,14 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
                                  int n_blocks, int span_total, float *partial, void *out)
 {
     const bool plain_chain = view.n_fx == 0 || (view.n_fx == 1 && view.fx_kind[0] == FX_FILTER);
-    if (view.mod_target != MT_NONE || !plain_chain || view.gated)
+    // synthesizer voices (oscillator x envelope under a mixer) have a gated form of the fast kernel
+    const bool fast_gated = env && !filt && view.n_fx == 0 &&
+                            (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
+    if (view.mod_target != MT_NONE || !plain_chain || (view.gated && !fast_gated))
         return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                  n_blocks, span_total, partial, out);
-    return launch_voice_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
-                               n_blocks, span_total, partial, out);
+    return launch_voice_kernel(env, filt, view.gated != 0, MODE, st, view, first, count, block_base,
+                               clock_base, n_blocks, span_total, partial, out);
 }
 
 static int check_external(klmi_bank *b, int n_blocks)

@@ -12,8 +12,8 @@ hipError_t upload_time_table_voice(const double *t);
 hipError_t upload_time_table_mod(const double *t);
 
 // grid = ceil(count / 256) workgroups; `mode` is an OutMode
-hipError_t launch_voice_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
-                               int first, int count, int block_base, uint32_t clock_base,
+hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStream_t st,
+                               const BankView &view, int first, int count, int block_base, uint32_t clock_base,
                                int n_blocks, int span_total, float *partial, void *out);
 hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                              int first, int count, int block_base, uint32_t clock_base,

@@ -8,7 +8,7 @@ hipError_t upload_time_table_voice(const double *t)
     return hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof(double) * kTimeSlots);
 }
 
-template <bool ENV, bool FILT, int MODE>
+template <bool ENV, bool FILT, int MODE, bool GATED = false>
 static hipError_t launch(hipStream_t st, const BankView &view, int first, int count, int block_base,
                          uint32_t clock_base, int n_blocks, int span_total, float *partial,
                          void *out)
@@ -17,7 +17,7 @@ static hipError_t launch(hipStream_t st, const BankView &view, int first, int co
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t smem = tile_bytes<MODE>();
-    auto kernel = voice_kernel<ENV, FILT, MODE>;
+    auto kernel = voice_kernel<ENV, FILT, MODE, GATED>;
     if (dev < 16 && !configured[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -32,10 +32,21 @@ static hipError_t launch(hipStream_t st, const BankView &view, int first, int co
 }
 
 template <int MODE>
-static hipError_t by_chain(bool env, bool filt, hipStream_t st, const BankView &view, int first,
-                           int count, int block_base, uint32_t clock_base, int n_blocks,
+static hipError_t by_chain(bool env, bool filt, bool gated, hipStream_t st, const BankView &view,
+                           int first, int count, int block_base, uint32_t clock_base, int n_blocks,
                            int span_total, float *partial, void *out)
 {
+    if (gated) {
+        // synthesizer voices: oscillator x envelope under a mixer (the caller sends every
+        // other gated shape to voice_mod_kernel)
+        if constexpr (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO) {
+            if (env && !filt)
+                return launch<true, false, MODE, true>(st, view, first, count, block_base,
+                                                       clock_base, n_blocks, span_total, partial,
+                                                       out);
+        }
+        return hipErrorInvalidValue;
+    }
     if (env && filt)
         return launch<true, true, MODE>(st, view, first, count, block_base, clock_base, n_blocks,
                                         span_total, partial, out);
@@ -49,13 +60,13 @@ static hipError_t by_chain(bool env, bool filt, hipStream_t st, const BankView &
                                       span_total, partial, out);
 }
 
-hipError_t launch_voice_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
-                               int first, int count, int block_base, uint32_t clock_base,
+hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStream_t st,
+                               const BankView &view, int first, int count, int block_base, uint32_t clock_base,
                                int n_blocks, int span_total, float *partial, void *out)
 {
 #define KLMI_MODE(M)                                                                          \
     case M:                                                                                   \
-        return by_chain<M>(env, filt, st, view, first, count, block_base, clock_base, n_blocks, \
+        return by_chain<M>(env, filt, gated, st, view, first, count, block_base, clock_base, n_blocks, \
                            span_total, partial, out)
     switch (mode) {
         KLMI_MODE(OUT_MIX_MONO);
