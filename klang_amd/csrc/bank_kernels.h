@@ -191,10 +191,43 @@ __device__ __forceinline__ void flush_chunk(typename TileTraits<MODE>::T *tile, 
     } else if constexpr (MODE == OUT_VOICES_F32 || MODE == OUT_VOICES_F64) {
         T *o = reinterpret_cast<T *>(out);
         const int base_local = blockIdx.x * kGroup + wave * 64;
-        for (int j = 0; j < 64; ++j) {
-            if (base_local + j < count) {
-                for (int r = lane; r < CH; r += 64)
-                    o[(size_t)(base_local + j) * span_total + s0 + r] = tile[r * TT::stride + j];
+        // A voice's CH samples are 256 contiguous bytes of its row.  16 lanes x 16 bytes cover
+        // one row, so a wavefront stores 4 rows per instruction (16 instead of 64 stores per
+        // chunk): all LDS reads first (one wait), then the stores back to back.  Rows that
+        // are not 16-byte aligned take the element-wise loop.
+        constexpr int E = 16 / (int)sizeof(T);   // elements per 16-byte store
+        static_assert(CH / E == 16, "16 lanes per voice row");
+        struct alignas(16) Pack {
+            T e[E];
+        };
+        const bool wide = ((reinterpret_cast<uintptr_t>(o) | ((size_t)span_total * sizeof(T))) & 15) == 0;
+        if (wide) {
+            const int q = lane >> 4, seg = lane & 15;
+            Pack pk[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+#pragma unroll
+                for (int k = 0; k < E; ++k)
+                    pk[it].e[k] = tile[(seg * E + k) * TT::stride + it * 4 + q];
+            }
+            T *row = o + (size_t)(base_local + q) * span_total + s0 + seg * E;
+            if (base_local + 64 <= count) {   // wave-uniform: a full tile
+#pragma unroll
+                for (int it = 0; it < 16; ++it)
+                    *reinterpret_cast<Pack *>(row + (size_t)(it * 4) * span_total) = pk[it];
+            } else {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    if (base_local + it * 4 + q < count)
+                        *reinterpret_cast<Pack *>(row + (size_t)(it * 4) * span_total) = pk[it];
+                }
+            }
+        } else {
+            for (int j = 0; j < 64; ++j) {
+                if (base_local + j < count) {
+                    for (int r = lane; r < CH; r += 64)
+                        o[(size_t)(base_local + j) * span_total + s0 + r] = tile[r * TT::stride + j];
+                }
             }
         }
     }
