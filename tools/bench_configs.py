@@ -68,7 +68,8 @@ def config2(ctx):
 
 def config3_materialised(ctx):
     import torch
-    n, n_blocks = 65536, int(os.environ.get('KLANG_BENCH_BLOCKS', '64'))   # override: experiments
+    # 256 blocks per launch as in the fused bench (a 17 GB float32 buffer); override: experiments
+    n, n_blocks = 65536, int(os.environ.get('KLANG_BENCH_BLOCKS', '256'))
     patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=n_blocks, off_base=min(10, n_blocks // 2),
                                          off_span=max(1, min(20, n_blocks // 3)))
     bank, ev = bank_for(ctx, patch)
