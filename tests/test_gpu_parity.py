@@ -510,3 +510,30 @@ def test_argument_errors(hip, ctx):
         hip.Bank(ctx, 0)
     with pytest.raises(hip.NativeError):
         hip.Context(99)
+
+
+def test_voice_rows_on_aligned_and_unaligned_device_buffers(hip, ctx):
+    """Per-voice output takes 16-byte stores (4 voice rows per instruction) when the rows are
+    16-byte aligned and an element-wise loop when they are not; a voice count that is no
+    multiple of 64 leaves a partial tile.  All of them must write the same rows: a caller's
+    device buffer at offsets of 0, 1 and 2 floats, 200 voices (3 full tiles + 8 voices),
+    rows compared bit for bit with the host-buffer call, guard words around the buffer intact."""
+    import torch
+    n, nb = 200, 3
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=1, off_span=2)
+    want = hip_bank_from_patch(hip, ctx, patch).render_voices(nb)
+    assert want.shape == (n, nb * B) and np.abs(want).max() > .1
+    for offset in (0, 1, 2):
+        bank = hip_bank_from_patch(hip, ctx, patch)
+        buf = torch.full((n * nb * B + 8,), 7., dtype=torch.float32, device='cuda')
+        view = buf[offset:offset + n * nb * B]
+        bank.render_voices_device(nb, view.data_ptr())
+        ctx.synchronize()
+        host = buf.cpu().numpy()
+        np.testing.assert_array_equal(host[offset:offset + n * nb * B].reshape(n, nb * B), want)
+        assert (host[:offset] == 7.).all() and (host[offset + n * nb * B:] == 7.).all()
+    # a sub-range of voices that starts inside a tile
+    bank = hip_bank_from_patch(hip, ctx, patch)
+    np.testing.assert_array_equal(bank.render_voices(nb, first=37, count=100), want[37:137])
+    np.testing.assert_array_equal(bank.render_voices(nb, first=0, count=n, f64=True).astype(np.float32),
+                                  want)
