@@ -390,6 +390,35 @@ def test_mixer_of_synthesizers_is_one_bank(hip, golden):
     banks[0].close()
 
 
+def test_stereo_mixer_of_synthesizers(hip, golden):
+    """Two 3-voice synthesizers panned left and right under
+    a StereoMixer (the gated fast kernel's stereo form): each channel is the fixture's
+    synthesizer output times its gain and constant-power pan amplitude."""
+    from klang_amd.audio import PolyphonicSynthesizer
+    from klang_amd.audio.mixers import panning_amplitudes
+    g = golden('synthesizer')
+    Poly3 = type('Poly3', (PolyphonicSynthesizer,), {'MAX_VOICES': 3})
+    a, b = Poly3(_synth_template(g)), Poly3(_synth_template(g))
+    mixer = StereoMixer()
+    mixer += a
+    mixer += b
+    mixer.gains[:] = [.9, 1.1]
+    mixer.pannings[:] = [-.6, .8]
+    order, banks = fusion.compile_order(determine_execution_order([mixer | Dac(nChannels=2)]))
+    assert [type(x).__name__ for x in order] == ['GpuVoiceBank', 'Dac'] and len(banks) == 1
+    n = len(g['poly3_out'])
+    shifted = g['poly3_notes'].copy()
+    shifted[:, 0] += 2
+    got = _play_compiled(order, [a, b], [g['poly3_notes'], shifted], n, mixer)   # [n][2][256]
+    late = np.concatenate([np.zeros((2, B)), g['poly3_out']])[:n]
+    pa = np.ravel(panning_amplitudes(-.6, mixer.mode, mixer.panLaw))
+    pb = np.ravel(panning_amplitudes(.8, mixer.mode, mixer.panLaw))
+    want = np.stack([(.9 * pa[c] * g['poly3_out'] + 1.1 * pb[c] * late) / 2 for c in (0, 1)], axis=1)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-6 and np.abs(want).max() > .05
+    banks[0].close()
+
+
 @pytest.mark.parametrize('policy', ['newest', 'lowest'])
 def test_monophonic_synthesizer_through_the_api(hip, golden, policy):
     from klang_amd.audio import MonophonicSynthesizer
