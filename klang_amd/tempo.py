@@ -34,6 +34,26 @@ THREE_FOUR_METRE = create_metre(3, 4)
 SIX_EIGHT_METRE = create_metre(6, 8)
 
 
+SEVEN_EIGHT_METRE = create_metre(7, 8)
+
+
+def is_irrational(metre):
+    """The denominator is no power of two (metre.py:55-61)."""
+    return metre.denominator & (metre.denominator - 1) != 0
+
+
+def is_simple(metre):
+    """Two, three or four beats (metre.py:87-88)."""
+    return metre.numerator in (2, 3, 4)
+
+
+def number_of_beats(metre, beatValue=None):
+    """metre.py:130-136."""
+    if beatValue is None:
+        beatValue = default_beat_value(metre)
+    return metre / beatValue
+
+
 def is_compound(metre):
     """6/8, 9/8, 12/8 ... (metre.py:80-84)."""
     return metre.numerator >= 6 and metre.numerator % 3 == 0

@@ -565,3 +565,26 @@ def test_temperament_known_answers(golden):
     for pitch, frequency in seen.items():
         assert Note(pitch).frequency == frequency
     assert Note(60, temperament=Temperament(np.arange(12) * 100, kammerton=432.)).frequency < 260.
+
+
+def test_metre_known_answers():
+    """tests/test_music_metre.py restated."""
+    from klang_amd import tempo as T
+    m = T.create_metre
+    assert (m(6, 4).numerator, m(6, 4).denominator) == (6, 4)
+    assert not T.is_irrational(m(3, 4)) and T.is_irrational(m(3, 5))
+    assert not any(T.is_complex(x) for x in (m(4, 4), m(3, 4), m(6, 8)))
+    assert T.is_complex(m(5, 4)) and T.is_complex(m(7, 8))
+    assert all(T.is_compound(x) for x in (m(6, 8), m(9, 8), m(12, 8)))
+    assert not T.is_compound(m(3, 4)) and not T.is_compound(m(4, 4))
+    assert all(T.is_simple(x) for x in (m(4, 4), m(3, 4), m(2, 4), m(3, 8), m(2, 2)))
+    assert not any(T.is_simple(x) for x in (m(6, 8), m(12, 8), m(9, 4)))
+    assert T.default_beat_value(T.FOUR_FOUR_METRE) == T.QUARTER_NOTE
+    assert T.default_beat_value(T.THREE_FOUR_METRE) == T.QUARTER_NOTE
+    assert T.default_beat_value(T.SIX_EIGHT_METRE) == T.DOTTED_QUARTER_NOTE
+    assert T.default_beat_value(T.SEVEN_EIGHT_METRE) == m(2, 8)
+    assert [T.number_of_beats(x) for x in (T.FOUR_FOUR_METRE, T.THREE_FOUR_METRE, T.SIX_EIGHT_METRE,
+                                           T.SEVEN_EIGHT_METRE)] == [4, 3, 2, 3.5]
+    assert T.number_of_beats(T.FOUR_FOUR_METRE, beatValue=T.EIGHT_NOTE) == 8
+    assert T.number_of_beats(T.SIX_EIGHT_METRE, beatValue=T.EIGHT_NOTE) == 6
+    assert T.number_of_beats(T.SEVEN_EIGHT_METRE, beatValue=T.EIGHT_NOTE) == 7
