@@ -1,7 +1,7 @@
 """A kick drum, a hi-hat, a bass line on a monophonic synthesizer and chords on a polyphonic
 one into one Mixer -- sources of four different kinds, so the Mixer takes their outputs as
 external voices -- with a ring modulator on the bass.  The hi-hat's white noise comes from
-NumPy's global RNG (as in the reference), so it stays a host block under backend='hip';
+NumPy's global RNG (as in the reference), drawn on the host under backend='hip' too;
 `build` seeds that RNG to make two bounces of the patch equal."""
 import numpy as np
 

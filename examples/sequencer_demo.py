@@ -1,10 +1,10 @@
 """The reference's sequencer demo (examples/sequencer_demo.py): a three-row pattern Sequencer
 drives a kick drum, a hi-hat and a polyphonic pad with a delay on it.
 
-The hi-hat is a host block (NumPy RNG noise), so this patch keeps its Sequencer on the host,
-buffer by buffer; `build(hihat=False)` leaves it out, and then an offline bounce runs the
-Sequencer ahead of the audio and hands the whole piece's notes to the device up front
-(klang_amd.klang.preschedule)."""
+Every row ends in a device block (the hi-hat's envelope runs on the device, its NumPy RNG
+noise is drawn on the host buffer by buffer), so an offline bounce runs the Sequencer ahead of
+the audio and hands the whole piece's notes to the device up front
+(klang_amd.klang.preschedule); `build(hihat=False)` leaves the hi-hat out."""
 import numpy as np
 
 from klang_amd.audio import (AR, Dac, Delay, HiHat, Kick, Oscillator, PolyphonicSynthesizer,

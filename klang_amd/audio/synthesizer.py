@@ -7,9 +7,10 @@ a sequential heap per instrument.
 
 ``Kick`` is mirrored with the reference's behaviour as it is: its
 ``currentPhase`` turns into a 256-vector after the first buffer
-(synthesizer.py:282 with waves.py:61).  ``HiHat`` is a host block only: its white
-noise comes from NumPy's global RNG, so it matches the reference exactly when the caller
-seeds ``np.random`` the same way, and there is no device form of that stream.
+(synthesizer.py:282 with waves.py:61).  ``HiHat``'s white noise comes from NumPy's
+global RNG, so it matches the reference exactly when the caller seeds ``np.random`` the same
+way; under ``backend='hip'`` its envelope runs on the device and the noise, still drawn here,
+goes in as the voice's external input (fusion.GpuHiHat).
 """
 import copy
 import heapq

@@ -93,7 +93,7 @@ def preschedule(execOrder, banks, n_cycles):
     for bank in banks:
         for inp, handle in bank.message_targets().items():
             targets[inp] = (bank, handle)
-    device = (fusion.GpuVoiceBank, fusion.GpuKick, fusion.GpuChirper, Adc, Dac)
+    device = (fusion.GpuVoiceBank, fusion.GpuKick, fusion.GpuChirper, fusion.GpuHiHat, Adc, Dac)
     hosts = [b for b in execOrder if not isinstance(b, device)]
     # the host blocks upstream of a device message input
     feeders = {inp.incomingConnection.owner for inp in targets if inp.incomingConnection}
@@ -149,7 +149,8 @@ def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
         n_cycles = None if duration == INF else int(duration * SAMPLING_RATE // BUFFER_SIZE)
         if kwargs.get('offline'):
             execOrder = preschedule(execOrder, banks, n_cycles)
-        # rendering ahead is safe when nothing on the host can emit a note between buffers
+        # rendering ahead is safe when nothing on the host can emit a note between buffers (a
+        # GpuHiHat draws its noise on the host, buffer by buffer: it keeps everything at 1)
         device_blocks = (fusion.GpuVoiceBank, fusion.GpuKick, fusion.GpuChirper, Adc, Dac)
         only_io = all(isinstance(b, device_blocks) for b in execOrder)
         ahead = (64 if only_io else 1) if lookahead is None else int(lookahead)

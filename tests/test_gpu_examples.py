@@ -18,7 +18,7 @@ B = 256
     ('hello_world', .3, 1, {}), ('haunting_envelopes', .5, 2, {}),
     ('reverberation_demo', 1.6, 1, {}), ('synthesizer_demo', 1.5, 1, {}),
     ('drum_machine', 2.2, 1, {}),
-    ('sequencer_demo', 2.5, 1, {}),                   # Sequencer stays on the host (HiHat)
+    ('sequencer_demo', 2.5, 1, {}),                   # with the hi-hat (noise drawn on the host)
     ('sequencer_demo', 2.5, 1, dict(hihat=False)),    # Sequencer run ahead, notes prescheduled
     ('arpeggiator_demo', 3., 1, {}),
     ('tempo_aware_effects', 2.5, 2, {}),
@@ -43,17 +43,32 @@ def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, chan
 
 
 def test_sequencer_is_run_ahead_for_an_offline_bounce(hip):
-    """With every note going to device blocks the Sequencer leaves the order (its notes are
-    queued on the device for the whole piece); with a host HiHat listening it stays."""
+    """Every note of the sequencer demo goes to device blocks (kick, hi-hat envelope,
+    synthesizer): the Sequencer leaves the order, its notes are queued on the device for the
+    whole piece.  With a host block listening to one of its rows it stays."""
     from examples import sequencer_demo
     from klang_amd import fusion
+    from klang_amd.block import Block
     from klang_amd.klang import preschedule
     from klang_amd.schedule import determine_execution_order
     from klang_amd.sequencing import Sequencer
-    for hihat, stays in ((False, False), (True, True)):
+    from klang_amd.wiring import MessageInput
+    for hihat in (False, True):
         order = determine_execution_order([sequencer_demo.build(hihat=hihat)])
         order, banks = fusion.compile_order(order, strict=True)
+        assert any(isinstance(b, fusion.GpuHiHat) for b in order) == hihat
         order = preschedule(order, banks, 300)
-        assert any(isinstance(b, Sequencer) for b in order) == stays
+        assert not any(isinstance(b, Sequencer) for b in order)
         for bank in banks:
             bank.close()
+    dac = sequencer_demo.build(hihat=False)
+    order = determine_execution_order([dac])
+    seq = next(b for b in order if isinstance(b, Sequencer))
+    listener = Block()
+    listener.inputs = [MessageInput(owner=listener)]
+    seq.outputs[0].connect(listener.input)
+    order = determine_execution_order([dac, listener])
+    order, banks = fusion.compile_order(order, strict=True)
+    assert any(isinstance(b, Sequencer) for b in preschedule(order, banks, 300))
+    for bank in banks:
+        bank.close()

@@ -271,3 +271,40 @@ def test_chirper_and_kick_through_the_api(hip):
     want = np.concatenate(run_klang(build(), offline=True, duration=dur, backend='host'))
     assert got.shape == want.shape and np.abs(want).max() > .3
     assert np.abs(got - want).max() <= 1e-6
+
+
+# ---- HiHat (synthesizer.py:222-250): envelope on the device, noise from the host RNG --------------
+@pytest.mark.parametrize('name,seed,kw', [('hihat_fresh', 1234, {}),
+                                          ('hihat_looped', 99, dict(decay=.12, loopedNoise=True))])
+def test_hihat_on_the_device_vs_reference(hip, golden, name, seed, kw):
+    """The reference's HiHat with NumPy's global RNG seeded as the fixture was: the device
+    block draws the same noise in the same order and multiplies it with the decay envelope
+    (float32 mix output vs the reference's float64 samples)."""
+    from klang_amd import fusion
+    from klang_amd.audio import Dac, HiHat
+    from klang_amd.messages import Note
+    from klang_amd.schedule import determine_execution_order
+    want = golden('synthesizer')[name + '_out']
+    state = np.random.get_state()
+    try:
+        np.random.seed(seed)
+        hat = HiHat(**kw)
+        order, banks = fusion.compile_order(determine_execution_order([hat | Dac()]))
+        assert [type(b).__name__ for b in order] == ['GpuHiHat', 'Dac']
+        out = []
+        for b in range(len(want)):
+            if b in (2, 30):
+                hat.input.push(Note(42))
+            if b == 35:
+                hat.input.push(Note(42, 0.))
+            for blk in order:
+                blk.update()
+            out.append(np.array(hat.output.value))
+    finally:
+        np.random.set_state(state)
+    err = np.abs(np.array(out) - want).max()
+    report('HiHat (device envelope x host noise)', err)
+    assert err <= 1e-6 and np.abs(want).max() > .5
+    banks[0].sync_host_blocks()
+    assert hat.envelope.stage == 0          # decayed to OFF by the end of the fixture
+    banks[0].close()
