@@ -1,7 +1,7 @@
 """examples/reverberation_demo.py of the reference (:11-34): three rhythmically interlaced
 monophonic synthesizers into a Mixer, the mix through a Reverb.  The reference's Sequencers
 are replaced by pre-written note scripts (same pitches, grids and note lengths at 120 bpm)."""
-from klang_amd.audio import AR, Dac, Mixer, MonophonicSynthesizer, Oscillator, Reverb, Voice
+from klang_amd.audio import AR, Dac, MonophonicSynthesizer, Oscillator, Reverb, Voice
 from klang_amd.messages import Note
 
 from examples import NoteScript

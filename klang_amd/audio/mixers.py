@@ -1,7 +1,5 @@
 """Mono and stereo mixers (klang/audio/mixer.py:15-104) and panning
 (klang/audio/panning.py:35-81), host side."""
-import numpy as np
-
 from klang_amd import native
 from klang_amd.audio.signals import MONO_SILENCE, STEREO_SILENCE
 from klang_amd.block import Block, fetch_output
@@ -17,6 +15,11 @@ def panning_amplitudes(panLevel, mode='constant_power', panLaw=None):
     """(2, 1) array of left/right amplitudes; ValueError for an unknown mode or
     a positive pan law (panning.py:49-52).  Computed by klmi_panning_amplitudes."""
     return native.panning_amplitudes(panLevel, mode, panLaw).reshape(2, 1)
+
+
+def pan_signal(signal, panLevel, mode='constant_power', panLaw=None):
+    """A mono signal -> stereo, or per-channel amplitudes on a stereo one (panning.py:84-99)."""
+    return panning_amplitudes(panLevel, mode, panLaw) * signal
 
 
 class Mixer(Block):

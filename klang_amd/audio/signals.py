@@ -73,6 +73,15 @@ WAVE_FUNCTIONS = {'sine': sine, 'square': square, 'sawtooth': sawtooth, 'triangl
 WAVE_IDS = {sine: 0, square: 1, sawtooth: 2, triangle: 3}
 
 
+def sample_wave(frequency, startPhase=0., wave_func=None, shape=BUFFER_SIZE):
+    """`shape` samples of a wave and the next start phase (waves.py:56-61; the Kick's
+    oscillator).  Unlike sample_phase the phase is not reduced before the wave function, and
+    with an array of frequencies the next start phase is an array too."""
+    t = get_time(shape)
+    phase = TAU * frequency * t + startPhase
+    return (wave_func or sine)(phase), wrap(phase[-1] + TAU * frequency * DT)
+
+
 def sample_phase(frequency, startPhase=0.):
     """BUFFER_SIZE phase samples and the next start phase (oscillators.py:41-67);
     scalar frequency or an array of BUFFER_SIZE frequencies."""

@@ -19,9 +19,9 @@ import math
 
 import numpy as np
 
-from klang_amd.audio.signals import DT, MONO_SILENCE, T
+from klang_amd.audio.signals import DT, MONO_SILENCE, T, sample_wave
 from klang_amd.config import BUFFER_SIZE
-from klang_amd.constants import PI, TAU
+from klang_amd.constants import PI
 from klang_amd.block import Block
 from klang_amd.wiring import MessageInput
 
@@ -211,6 +211,5 @@ class Kick(Block):
         frequency, _ = sample_pitch_decay(self.frequency, self.pitchDecay, self.intensity,
                                           self.currentTime)
         env, self.currentTime = sample_exponential_decay(self.decay, self.currentTime)
-        phase = TAU * frequency * T + self.currentPhase                      # waves.py:60
-        self.currentPhase = (phase[-1] + TAU * frequency * DT + PI) % TAU - PI  # waves.py:61
-        self.output.set_value(env * np.sin(phase))
+        signal, self.currentPhase = sample_wave(frequency, startPhase=self.currentPhase)
+        self.output.set_value(env * signal)

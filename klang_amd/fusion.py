@@ -33,8 +33,6 @@ mixer's own ``Output`` object, so downstream connections are untouched.
 There is no fallback: under ``backend='hip'`` a hot-path block that cannot be
 fused is an error, and a missing library or GPU raises from klang_amd.native.
 """
-from fractions import Fraction
-
 import numpy as np
 
 from klang_amd import native

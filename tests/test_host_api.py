@@ -588,3 +588,22 @@ def test_metre_known_answers():
     assert T.number_of_beats(T.FOUR_FOUR_METRE, beatValue=T.EIGHT_NOTE) == 8
     assert T.number_of_beats(T.SIX_EIGHT_METRE, beatValue=T.EIGHT_NOTE) == 6
     assert T.number_of_beats(T.SEVEN_EIGHT_METRE, beatValue=T.EIGHT_NOTE) == 7
+
+
+def test_sample_wave_and_pan_signal():
+    """waves.py:56-61 and panning.py:84-99: the un-reduced phase of sample_wave (the Kick's
+    oscillator) and the amplitudes pan_signal applies."""
+    from klang_amd.audio.mixers import pan_signal, panning_amplitudes
+    from klang_amd.audio.signals import DT, T, sample_wave, sawtooth, wrap
+    from klang_amd.constants import TAU
+    x, nxt = sample_wave(440., startPhase=.5)
+    np.testing.assert_array_equal(x, np.sin(TAU * 440. * T + .5))
+    assert nxt == wrap((TAU * 440. * T + .5)[-1] + TAU * 440. * DT) and -np.pi <= nxt < np.pi
+    y, _ = sample_wave(100., wave_func=sawtooth, shape=16)
+    assert y.shape == (16,)
+    freqs = np.linspace(40., 80., 256)
+    _, nxt = sample_wave(freqs)
+    assert np.shape(nxt) == (256,)          # an array of frequencies gives an array of phases
+    sig = np.arange(4.)
+    np.testing.assert_array_equal(pan_signal(sig, .3), panning_amplitudes(.3) * sig)
+    assert pan_signal(sig, -1.).shape == (2, 4)
