@@ -33,6 +33,9 @@ mixer's own ``Output`` object, so downstream connections are untouched.
 There is no fallback: under ``backend='hip'`` a hot-path block that cannot be
 fused is an error, and a missing library or GPU raises from klang_amd.native.
 """
+import copy
+import types
+
 import numpy as np
 
 from klang_amd import native
@@ -50,6 +53,7 @@ from klang_amd.block import Block
 from klang_amd.composite import Composite
 from klang_amd.errors import KlangError
 from klang_amd.tempo import compute_rate
+from klang_amd.wiring import Output
 
 EFFECT_KINDS = {Filter: native.FX_FILTER, Gain: native.FX_GAIN, Transformer: native.FX_TRANSFORM,
                 TanhDistortion: native.FX_TANH, OctaveDistortion: native.FX_OCTAVE,
@@ -214,6 +218,17 @@ class Chain:
         return WAVE_IDS[self.oscillator.wave_func]
 
 
+class _ChannelTap:
+    """One row of somebody's multi-channel output, as the external source of a chain."""
+
+    def __init__(self, output, channel):
+        self.output, self.channel, self.owner = output, channel, output.owner
+
+    @property
+    def value(self):
+        return np.asarray(self.output.value)[self.channel]
+
+
 class GpuVoiceBank(Block):
     """A fused set of chains evaluated by one device bank.  `sink` is the block
     whose output carries the result (the mixer, or the chain end itself)."""
@@ -244,6 +259,14 @@ class GpuVoiceBank(Block):
             # mean over the synthesizers of (sum of voices / MAX_VOICES): mixer.py:46-47 after
             # synthesizer.py:219
             self.bank.set_mix_divisor(float(self.poly * len(self.synths)))
+        # A StereoMixer that takes its inputs as external voices gives every input TWO voices:
+        # a mono input uses the first (gain, pan as set), a stereo input (pan amplitudes per
+        # channel, mixer.py:95-99) uses both, hard left and hard right.
+        self.pairs = bool(self.stereo and all(c.end is None for c in chains))
+        if self.pairs:
+            self.bank.set_mix_divisor(float(max(1, len(chains) // 2)) if len(chains) > 2 else 1.)
+            self._pair_state = None
+        self._twins = []        # banks for channels 1.. of a chain fed with a multi-channel signal
         self.lookahead = 1      # blocks rendered per device call (set by run_klang)
         self.remaining = None   # buffers still to be delivered, when the caller knows (offline
                                 # bounce): rendering ahead never runs past the end of the piece
@@ -295,7 +318,7 @@ class GpuVoiceBank(Block):
         self._fx_params = {}
         for s in range(len(self.program)):
             self._upload_stage(s, force=True)
-        if self.is_mixer:
+        if self.is_mixer and not self.pairs:
             bank.set(F.F_GAIN, self._per_voice(self.sink.gains))
             if self.stereo:
                 bank.set(F.F_PAN, self._per_voice(self.sink.pannings))
@@ -390,7 +413,7 @@ class GpuVoiceBank(Block):
                 bank.event(i, 0, F.EV_SET_CUTOFF, 0., float(self._cutoffs[i]))
         for s in range(len(self.program)):
             self._upload_stage(s)
-        if self.is_mixer:
+        if self.is_mixer and not self.pairs:
             if list(self.sink.gains) != self._gains:
                 self._gains = list(self.sink.gains)
                 bank.set(F.F_GAIN, self._per_voice(self._gains))
@@ -421,6 +444,12 @@ class GpuVoiceBank(Block):
         if self.remaining is not None:
             self.remaining -= 1
         self.sink.output.set_value(self._ready.pop().astype(np.float64))
+        if self._twins:
+            rows = [self.sink.output.value]
+            for twin in self._twins:
+                twin.update()
+                rows.append(twin.sink.output.value)
+            self.sink.output.set_value(np.stack(rows))
 
     # -- notes known ahead of time (klang_amd.klang.preschedule) ---------------------------
     def message_targets(self):
@@ -451,8 +480,57 @@ class GpuVoiceBank(Block):
             self.bank.event(i, block, F.EV_NOTE_OFF)
             voice.currentPitch = 0
 
+    def _split_channels(self, n_channels):
+        """The chain's source turned out to carry n_channels: every channel gets a bank of its
+        own over the same stage blocks (same parameters, same initial state), as the host
+        blocks treat the rows of a multi-channel buffer alike (effects.py:365-384 for Filter)."""
+        chain = self.chains[0]
+        source = chain.external
+        for ch in range(1, n_channels):
+            twin_chain = copy.copy(chain)
+            twin_chain.external = _ChannelTap(source, ch)
+            twin = GpuVoiceBank([twin_chain], types.SimpleNamespace(output=Output()), self.ctx)
+            self._twins.append(twin)
+        chain.external = _ChannelTap(source, 0)
+
+    def _feed_pairs(self):
+        """StereoMixer over external voices, two voices per input (see __init__)."""
+        F, sink = native, self.sink
+        rows, gains, pans = [], [], []
+        hard_l = float(native.panning_amplitudes(-1., sink.mode, sink.panLaw)[0])
+        hard_r = float(native.panning_amplitudes(1., sink.mode, sink.panLaw)[1])
+        silence = np.zeros(BUFFER_SIZE)
+        for i in range(0, len(self.chains), 2):
+            value = np.asarray(self.chains[i].external.value, dtype=np.float64)
+            gain, pan = float(sink.gains[i // 2]), float(sink.pannings[i // 2])
+            if value.shape == (BUFFER_SIZE,):
+                rows += [value, silence]
+                gains += [gain, 0.]
+                pans += [pan, 0.]
+            elif value.shape == (2, BUFFER_SIZE) and hard_l > 0. and hard_r > 0.:
+                amp = native.panning_amplitudes(pan, sink.mode, sink.panLaw)
+                rows += [value[0], value[1]]
+                gains += [gain * float(amp[0]) / hard_l, gain * float(amp[1]) / hard_r]
+                pans += [-1., 1.]
+            else:
+                raise KlangError('%s: input %d carries a buffer of shape %s from %s'
+                                 % (self, i // 2, value.shape, self.chains[i].external.owner))
+        if (gains, pans) != self._pair_state:
+            self._pair_state = (gains, pans)
+            self.bank.set(F.F_GAIN, gains)
+            self.bank.set(F.F_PAN, pans)
+        self.bank.set_input(np.stack(rows))
+
     def _feed_external(self):
         """This buffer's samples of the chains' sources -> klmi_bank_set_input."""
+        if self.pairs:
+            return self._feed_pairs()
+        if not self.is_mixer and len(self.chains) == 1 and not self._twins:
+            c = self.chains[0]
+            value = np.asarray(c.external.value)
+            if (value.ndim == 2 and c.reverb is None
+                    and not (c.stages and type(c.stages[0]) is Delay)):
+                self._split_channels(value.shape[0])
         rows = []
         for c in self.chains:
             value = np.asarray(c.external.value, dtype=np.float64)
@@ -525,6 +603,8 @@ class GpuVoiceBank(Block):
                 c.oscillator.frequency.set_value(float(freq[i]))
 
     def close(self):
+        for twin in self._twins:
+            twin.close()
         self.bank.close()
 
     def __str__(self):
@@ -754,6 +834,10 @@ def find_fusable(exec_order):
                 chains = [Chain(s) for s in sources]
                 if len({c.shape for c in chains}) != 1:
                     raise NotFusable('%s mixes chains of different shapes' % blk)
+                if isinstance(blk, StereoMixer) and chains[0].external is not None:
+                    # chains fed from outside may carry stereo buffers: each becomes a bank of
+                    # its own (one per channel if need be), the mixer takes their outputs
+                    raise NotFusable('%s: externally fed chains under a StereoMixer' % blk)
                 groups.append((blk, chains, ()))
                 claimed.update(b for c in chains for b in c.blocks)
                 claimed.add(blk)
@@ -763,7 +847,8 @@ def find_fusable(exec_order):
                 # (or not) on its own further down.
                 outputs = [inp.incomingConnection for inp in blk.inputs]
                 if all(o is not None and o.owner is not None for o in outputs):
-                    groups.append((blk, [Chain(external=o) for o in outputs], ()))
+                    per_input = 2 if isinstance(blk, StereoMixer) else 1   # see GpuVoiceBank.pairs
+                    groups.append((blk, [Chain(external=o) for o in outputs for _ in range(per_input)], ()))
                     claimed.add(blk)
                 else:
                     errors.append(str(err))

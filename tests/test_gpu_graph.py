@@ -329,6 +329,54 @@ def test_stereo_delay_is_opened_and_its_delays_run_on_the_device(hip, golden, st
     assert report('StereoDelay (two device delay lines)', np.abs(got - want).max()) <= 1e-5
 
 
+def _stereo_signal_patches():
+    from klang_amd.audio import (AudioCombiner, Bitcrusher, Gain, StereoDelay, TanhDistortion,
+                                 Tremolo)
+
+    def stereo_source():
+        comb = AudioCombiner(nInputs=2)
+        Oscillator(220., wave_func=sawtooth) | comb.inputs[0]
+        Oscillator(331., wave_func=sine) | comb.inputs[1]
+        return comb
+
+    def stages_on_stereo():     # every channel of a stereo buffer runs through the stages
+        return (stereo_source() | Tremolo(rate=5., depth=.7, smoothness=.4) | Filter(frequency=900.)
+                | TanhDistortion(1.5) | Gain(.8) | Dac(nChannels=2))
+
+    def stereo_into_stereo_mixer():   # aeolian_arp.py:45-98: StereoDelay / Tremolo outputs + mono
+        mixer = StereoMixer()
+        mixer += (Oscillator(110., wave_func=sawtooth)
+                  | StereoDelay(leftTime=.03, rightTime=.05, leftFeedback=.6, rightFeedback=.4))
+        mixer += Oscillator(440.) | Bitcrusher(6)
+        mixer += stereo_source() | Tremolo(rate=3., depth=1., smoothness=.01)
+        mixer.gains = [2., .2, 1.]
+        mixer.pannings = [0., -.5, .3]
+        return mixer | Dac(nChannels=2)
+
+    def single_stereo_input():        # one input: no division (mixer.py:101-102)
+        mixer = StereoMixer()
+        mixer += stereo_source() | Gain(.5)
+        mixer.pannings = [.4]
+        return mixer | Dac(nChannels=2)
+
+    return dict(stages_on_stereo=stages_on_stereo, stereo_into_stereo_mixer=stereo_into_stereo_mixer,
+                single_stereo_input=single_stereo_input)
+
+
+@pytest.mark.parametrize('name', ['stages_on_stereo', 'stereo_into_stereo_mixer',
+                                  'single_stereo_input'])
+def test_stereo_signals_through_device_chains_and_mixers(hip, name):
+    """A stereo buffer fed into effect stages runs as one device chain per channel; a
+    StereoMixer takes stereo inputs as two hard-panned voices with the pan amplitudes in their
+    gains (mixer.py:95-99).  Against the host evaluation of the same blocks."""
+    build = _stereo_signal_patches()[name]
+    dur = 40 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0.))
+    want = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert got.shape == want.shape == (40 * B, 2) and np.abs(want).max() > .05
+    assert report('stereo signal: ' + name, np.abs(got - want).max()) <= 1e-5
+
+
 # ---- synthesizers (SURVEY 8f rank 3) -------------------------------------------------------
 def _synth_template(g):
     return Voice(Oscillator(wave_func=sawtooth), ADSR(*[float(x) for x in g['template']]))
