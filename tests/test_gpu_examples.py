@@ -22,7 +22,8 @@ B = 256
     ('sequencer_demo', 2.5, 1, dict(hihat=False)),    # Sequencer run ahead, notes prescheduled
     ('arpeggiator_demo', 3., 1, {}),
     ('tempo_aware_effects', 2.5, 2, {}),
-    ('micro_rhythm_demo', 3., 1, dict(rate=.5))])        # note-value rates and times, StereoDelay opened
+    ('micro_rhythm_demo', 3., 1, dict(rate=.5)),
+    ('aeolian_arp', 3., 2, {})])                  # stereo signals through chains and the mixer        # note-value rates and times, StereoDelay opened
 def test_example_matches_the_host_evaluation(hip, tmp_path, name, duration, channels, kwargs):
     mod = importlib.import_module('examples.' + name)
     out = {}
