@@ -505,3 +505,27 @@ def test_host_stereo_delay_vs_golden(golden, stereo, key):
         for blk in order:
             blk.update()
         np.testing.assert_array_equal(sd.output.value, want[b])
+
+
+def test_fuser_plans_for_stereo_signals():
+    """A StereoMixer that takes its inputs as external voices gets two voices per input (a
+    stereo input needs both); externally fed chains under a StereoMixer stay banks of their
+    own, because their source may turn out to be stereo; a StereoDelay is opened."""
+    from klang_amd.audio import AudioCombiner, Bitcrusher, StereoDelay, Tremolo
+    comb = AudioCombiner(nInputs=2)
+    Oscillator(220., wave_func=sawtooth) | comb.inputs[0]
+    Oscillator(331.) | comb.inputs[1]
+    mixer = StereoMixer()
+    mixer += Oscillator(110., wave_func=sawtooth) | StereoDelay(leftTime=.03, rightTime=.05)
+    mixer += Oscillator(440.) | Bitcrusher(6)
+    mixer += comb | Tremolo(rate=3.)
+    order = fusion.open_composites(determine_execution_order([mixer | Dac(nChannels=2)]))
+    assert 'StereoDelay' not in [type(b).__name__ for b in order]
+    groups, errors = fusion.find_fusable(order)
+    assert not errors
+    by_sink = {type(sink).__name__: chains for sink, chains, _ in groups}
+    assert len(by_sink['StereoMixer']) == 6 and all(c.end is None for c in by_sink['StereoMixer'])
+    owners = [inp.incomingConnection.owner for inp in mixer.inputs]
+    assert [c.external.owner for c in by_sink['StereoMixer'][::2]] == owners
+    assert by_sink['Tremolo'][0].external.owner is comb
+    assert len([s for s, _, _ in groups if type(s).__name__ == 'Delay']) == 2
