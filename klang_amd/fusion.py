@@ -25,6 +25,11 @@ samples arrive per buffer as the bank's external input (KLMI_WAVE_EXTERNAL).
 ``PolyphonicSynthesizer`` / ``MonophonicSynthesizer`` blocks, alone
 or as the inputs of one mixer, become *gated* banks: one voice per synthesizer voice,
 updated only while active; the polyphonic note routing runs on the device.
+``Kick``, ``Chirper`` and ``HiHat`` blocks become device blocks of their own (the hi-hat's
+RNG noise is drawn on the host and enters as external input).  Composites that merely run
+their inner blocks (``StereoDelay``) are opened first, so that their stages are seen.  A
+stereo buffer fed into a chain of stages runs one bank per channel; a ``StereoMixer`` over
+external voices takes stereo inputs as two hard-panned voices.
 Chains that end anywhere else (``Oscillator(440.) | Dac()``) become one-voice
 banks.  Per buffer the bank block drains the voices' note queues into
 block-boundary events (voices.py:55-64), renders, and publishes the mix on the
