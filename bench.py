@@ -95,8 +95,26 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    # KLANG_BENCH_REHEARSE=1: a rehearsal of the N>1 path on a ONE-GPU box -- every rank on
+    # device 0, the bus reduce through gloo on host copies.  It checks the sharded patch, the
+    # event upload, the barriers and the timing protocol; its numbers mean nothing.
+    rehearse = world > 1 and os.environ.get('KLANG_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if rehearse:
+        from klang_amd import sharding
+        dist.init_process_group('gloo')
+
+        def reduce_via_host(bus, n_total, world_size, dst=0, group=None):
+            host = bus.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            bus.copy_(host)
+            if n_total > 1:
+                bus /= float(n_total)
+            return bus
+        sharding.reduce_bus = reduce_via_host
+    elif world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     n_total = VOICES_PER_GPU * world
