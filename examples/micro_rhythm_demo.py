@@ -1,31 +1,29 @@
-"""The reference's micro rhythm demo (examples/micro_rhythm_demo.py): a kick drum and a hi-hat
-from one Sequencer; the hi-hat row's phase runs through a MicroRhyhtm whose phrasing a slow Lfo
-moves between straight and grooved.  apply_micro_rhythm comes last, so that the Lfo lands in
-the Sequencer's own execution order."""
+"""The reference's micro rhythm demo (examples/micro_rhythm_demo.py there): one Sequencer plays
+a kick drum row and a straight sixteenth hi-hat row; the hi-hat row's bar phase runs through
+a MicroRhyhtm (eighth, two sixteenths, eighth) whose phrasing a slow triangle Lfo moves
+between straight and grooved.  The micro rhythm is applied after everything else is patched,
+so that the Lfo lands in the Sequencer's own execution order."""
 import numpy as np
 
+from klang_amd import tempo
 from klang_amd.audio import Dac, HiHat, Kick, Lfo, triangle
 from klang_amd.sequencing import MicroRhyhtm, Sequencer
-from klang_amd.tempo import EIGHT_NOTE, SIXTEENTH_NOTE
 
-TEMPO = 80
-PATTERN = [
-    [60, 0, 0, 0, 60, 0, 0, 0, 60, 0, 0, 0, 60, 0, 0, 60],   # kick drum
-    4 * [60, 60, 60, 60],                                    # hi-hat
-]
-MICRO_RHYTHM_NOTES = [EIGHT_NOTE, SIXTEENTH_NOTE, SIXTEENTH_NOTE, EIGHT_NOTE]
-RATE = .05
+BPM = 80
+KICK_ROW = [60 if k in (0, 4, 8, 12, 15) else 0 for k in range(16)]
+HAT_ROW = [60] * 16
+GROOVE = [tempo.EIGHT_NOTE, tempo.SIXTEENTH_NOTE, tempo.SIXTEENTH_NOTE, tempo.EIGHT_NOTE]
 
 
-def build(rate=RATE, seed=11):
+def build(rate=.05, seed=11):
     np.random.seed(seed)   # the hi-hat's noise (NumPy's global RNG)
-    sequencer = Sequencer(PATTERN, tempo=TEMPO)
-    mixer = (sequencer.outputs[0] | Kick()) + (sequencer.outputs[1] | HiHat())
+    sequencer = Sequencer([KICK_ROW, HAT_ROW], tempo=BPM)
+    kick_row, hat_row = sequencer.outputs
+    mixer = (kick_row | Kick()) + (hat_row | HiHat())
     mixer.gains = [1., .2]
-    lfo = Lfo(frequency=rate, wave_func=triangle)
-    mr = MicroRhyhtm(MICRO_RHYTHM_NOTES)
-    lfo | mr.phrasing
-    sequencer.apply_micro_rhythm(mr, channel=1)
+    groove = MicroRhyhtm(GROOVE)
+    Lfo(frequency=rate, wave_func=triangle) | groove.phrasing
+    sequencer.apply_micro_rhythm(groove, channel=1)
     return mixer | Dac()
 
 
