@@ -607,3 +607,62 @@ def test_sample_wave_and_pan_signal():
     sig = np.arange(4.)
     np.testing.assert_array_equal(pan_signal(sig, .3), panning_amplitudes(.3) * sig)
     assert pan_signal(sig, -1.).shape == (2, 4)
+
+
+def test_mixer_add_operators():
+    """tests/test_audio_mixer.py:16-53: Mixer + thing and thing + Mixer for inputs (refused),
+    outputs, blocks without an output (refused) and blocks."""
+    with pytest.raises(IncompatibleConnection):
+        Mixer(nInputs=0) + Block(1, 1).input
+    mixer, block = Mixer(nInputs=0), Block(1, 1)
+    assert (mixer + block.output) is mixer and connected(block, mixer.inputs[0])
+    with pytest.raises(AttributeError):
+        Mixer(nInputs=0) + Block()
+    mixer, block = Mixer(nInputs=0), Block(1, 1)
+    assert (mixer + block) is mixer and connected(block, mixer.inputs[0])
+    with pytest.raises(IncompatibleConnection):
+        Block(1, 1).input + Mixer(nInputs=0)
+    mixer, block = Mixer(nInputs=0), Block(1, 1)
+    assert (block.output + mixer) is mixer and connected(block, mixer.inputs[0])
+    with pytest.raises(AttributeError):
+        Block() + Mixer(nInputs=0)
+    mixer, block = Mixer(nInputs=0), Block(1, 1)
+    assert (block + mixer) is mixer and connected(block, mixer.inputs[0])
+
+
+def test_execution_order_edge_cases_and_queue_reads():
+    """tests/test_execution.py:8-36 (no blocks, one block, unconnected blocks in the given order,
+    a second network reached through a connection) and tests/test_connections.py:167-190
+    (receive drains in order, receive_latest returns the newest and clears the queue)."""
+    assert determine_execution_order([]) == []
+    block = Block()
+    assert determine_execution_order([block]) == [block]
+    a, b, c = Block(1, 1), Block(1, 1), Block(1, 1)
+    assert determine_execution_order([a, b, c]) == [a, b, c]
+    a, b, c = Block(1, 1), Block(1, 1), Block(1, 1)
+    b.output.connect(c.input)
+    assert determine_execution_order([a, b]) == [a, b, c]
+    inp = MessageInput()
+    for msg in range(10):
+        inp.push(msg)
+    assert len(inp.queue) == 10 and list(inp.receive()) == list(range(10)) and len(inp.queue) == 0
+    assert inp.receive_latest() is None
+    for msg in range(10):
+        inp.push(msg)
+    assert inp.receive_latest() == 9 and len(inp.queue) == 0
+    from klang_amd.wiring import InputBase, OutputBase, RelayBase
+    relay = RelayBase()
+    OutputBase().connect(relay)
+    with pytest.raises(InputAlreadyConnected):
+        OutputBase().connect(relay)
+
+
+def test_temporarily_unpatch_restores_every_connection():
+    """tests/test_composite.py:9-23."""
+    src, block, dst0, dst1 = Block(0, 1), Block(1, 1), Block(1, 0), Block(1, 0)
+    src | block | dst0
+    block | dst1
+    with temporarily_unpatch(block):
+        assert not block.input.connected and not block.output.connected
+    assert block.input.incomingConnection is src.output
+    assert set(block.output.outgoingConnections) == {dst0.input, dst1.input}
