@@ -51,6 +51,9 @@ def _compatible(src, dst):
     return src.flavour == dst.flavour and type(src) in _KNOWN and type(dst) in _KNOWN
 
 
+is_valid_connection = _compatible   # the reference's public name (connections.py:41)
+
+
 def _require_compatible(src, dst):
     if not _compatible(src, dst):
         raise IncompatibleConnection('Can not connect %s with %s!'

@@ -666,3 +666,13 @@ def test_temporarily_unpatch_restores_every_connection():
         assert not block.input.connected and not block.output.connected
     assert block.input.incomingConnection is src.output
     assert set(block.output.outgoingConnections) == {dst0.input, dst1.input}
+
+
+def test_is_valid_connection_table():
+    """tests/test_connections.py:192-207."""
+    from klang_amd.wiring import InputBase, OutputBase, RelayBase, is_valid_connection as valid
+    assert valid(OutputBase(), InputBase()) and valid(OutputBase(), RelayBase())
+    assert valid(RelayBase(), RelayBase()) and valid(RelayBase(), InputBase())
+    assert not valid(InputBase(), InputBase()) and not valid(OutputBase(), OutputBase())
+    assert not valid(MessageOutput(), InputBase()) and not valid(MessageOutput(), RelayBase())
+    assert not valid(OutputBase(), MessageInput()) and not valid(RelayBase(), MessageInput())
