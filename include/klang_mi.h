@@ -305,6 +305,31 @@ int klmi_bank_set_input(klmi_bank *bank, const double *host_x, int n_blocks);
 int klmi_bank_render(klmi_bank *bank, int n_blocks, float *host_mix);
 int klmi_bank_render_device(klmi_bank *bank, int n_blocks, float *dev_mix);
 
+/* klmi_bank_render_device without any allocation.  It has no counterpart in the
+ * reference: it is for callers that cannot allocate -- code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  The per-wave partial buses and
+ * the slice sums of the bus fold, which klmi_bank_render_device keeps in buffers that grow
+ * with the call, live in ONE static device array of KLMI_NOALLOC_SCRATCH_BYTES per GPU
+ * (held by every GPU the library runs on until the process ends); the call makes no
+ * hipMalloc / hipFree and no allocating library call.  Same kernels, same fold order:
+ * the bus is bit-identical to klmi_bank_render_device's, state and queues advance alike.
+ * Limits, each reported with a clear error and nothing rendered:
+ *   - one buffer of the bank must fit the array (n_voices * channels * 16 bytes + at
+ *     most 64 KiB * channels; 4,128,768 voices mono): KLMI_E_ARG; longer calls are split
+ *     into as many launches as the array requires;
+ *   - reverb banks (their dry bus and rings are sized per call): KLMI_E_STATE;
+ *   - events / notes queued since the last render must fit the device queues already
+ *     uploaded, and a Delay stage's lines must exist (one allocating render or preview
+ *     first): KLMI_E_STATE;
+ *   - klmi_bank_last_kernel_ms reports 0 launches after it (timing events are created
+ *     on demand by the allocating calls only).
+ * Every call on a GPU shares that GPU's array, whatever bank or context it comes from:
+ * calls that overlap in time on one GPU (different streams or threads) race; calls
+ * ordered on one stream do not.  Nothing in the array has to start at zero -- each launch
+ * overwrites every element it later reads. */
+#define KLMI_NOALLOC_SCRATCH_BYTES (64u << 20)
+int klmi_bank_render_device_noalloc(klmi_bank *bank, int n_blocks, float *dev_mix);
+
 /* Materialise per-voice streams (Output.value of the fused chain's last block
  * for voices [first, first+count)): out[count][n_blocks*256].  A *preview*:
  * state and the event queue are left untouched, so the next klmi_bank_render

@@ -193,9 +193,21 @@ template <typename T> struct DevBuf {
 }  // namespace
 
 // ---------------------------------------------------------------------------------
+// scratch of klmi_bank_render_device_noalloc, the entry point that allocates nothing:
+// the per-wave partial buses and the slice sums of the bus fold live here instead of in
+// hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy of the array (at
+// its own address) until the process ends.  In host code `scratch` is only a stand-in for
+// the symbol: klmi_ctx_create asks the device for the address (hipGetSymbolAddress, once
+// per context, with that device current) and everything below uses that pointer.
+// ---------------------------------------------------------------------------------
+constexpr size_t kScratchBytes = KLMI_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+// ---------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------
 struct klmi_ctx {
+    unsigned char *scratch_ptr = nullptr;  // device address of `scratch` on this context's GPU
     int device = 0;
     hipStream_t stream = nullptr;
     int live_objects = 0;            // banks / batches created on this context
@@ -265,6 +277,13 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         e = upload_time_table_voice(t);
     if (e == hipSuccess)
         e = upload_time_table_mod(t);
+    if (e == hipSuccess) {
+        void *p = nullptr;  // this device's copy of the scratch array (the device is current)
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        ctx->scratch_ptr = static_cast<unsigned char *>(p);
+        if (e == hipSuccess && !p)
+            e = hipErrorInvalidSymbol;
+    }
     if (e != hipSuccess) {
         delete ctx;
         return fail(KLMI_E_DEVICE, "context setup failed: %s", hipGetErrorString(e));
@@ -615,7 +634,7 @@ static int upload_fx(klmi_bank *b, int stage, int first, int count)
 
 // The delay stage's lines [n][stride], stride >= the longest line of the bank + 8 mirror
 // slots; (re)allocated zeroed when the capacity changed (ring_buffer.py:42 zero-initialised).
-static int ensure_fx_ring(klmi_bank *b)
+static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
 {
     if (b->fx_delay_stage < 0)
         return 0;
@@ -626,6 +645,9 @@ static int ensure_fx_ring(klmi_bank *b)
                                   KLMI_SAMPLING_RATE));
     if (cap == b->fx_ring_cap)
         return 0;
+    if (!may_alloc)
+        return fail(KLMI_E_STATE, "the Delay stage's lines are not allocated yet (or their length "
+                                  "changed): one allocating render (or preview) must come first");
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     b->fx_ring.release();
     b->fx_ring_backup.release();
@@ -1209,7 +1231,7 @@ extern "C" int klmi_bank_set_input(klmi_bank *b, const double *host_x, int n_blo
 // been consumed (block < clock), stable-sort by (voice, block), build the
 // per-voice CSR, reset the per-voice cursors.  Renders with an unchanged queue
 // do no host-side event work at all.
-static int sync_events(klmi_bank *b)
+static int sync_events(klmi_bank *b, bool may_alloc = true)
 {
     if (!b->events_dirty)
         return 0;
@@ -1236,6 +1258,10 @@ static int sync_events(klmi_bank *b)
     for (int v = 0; v < b->n; ++v)
         offset[v + 1] += offset[v];
     hipStream_t st = b->ctx->stream;
+    if (!may_alloc && m > b->ev_block.n)
+        return fail(KLMI_E_STATE, "%zu queued events do not fit the %zu uploaded so far: the "
+                                  "device queue would have to grow; queue them before an "
+                                  "allocating render", m, b->ev_block.n);
     HIP_TRY(hipStreamSynchronize(st));  // nothing in flight may still read the old arrays
     HIP_TRY(b->ev_block.reserve(m));
     HIP_TRY(b->ev_kind.reserve(m));
@@ -1263,7 +1289,7 @@ static int sync_events(klmi_bank *b)
 }
 
 // The same for the notes of a polyphonic bank, CSR by instrument.
-static int sync_notes(klmi_bank *b)
+static int sync_notes(klmi_bank *b, bool may_alloc = true)
 {
     if (!b->notes_dirty)
         return 0;
@@ -1289,6 +1315,10 @@ static int sync_notes(klmi_bank *b)
     for (size_t k = 0; k < n_inst; ++k)
         offset[k + 1] += offset[k];
     hipStream_t st = b->ctx->stream;
+    if (!may_alloc && m > b->nt_block.n)
+        return fail(KLMI_E_STATE, "%zu queued notes do not fit the %zu uploaded so far: the "
+                                  "device queue would have to grow; queue them before an "
+                                  "allocating render", m, b->nt_block.n);
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(b->nt_block.reserve(m));
     HIP_TRY(b->nt_pitch.reserve(m));
@@ -1362,14 +1392,18 @@ static int timing_begin(klmi_bank *b, int idx)
 
 static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix);
 
-static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix)
+// `fixed`: a caller-supplied workspace of `fixed_bytes` (the static scratch array) instead of
+// the bank's own growing buffers; nothing is allocated then, and the launches are not timed.
+static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix, unsigned char *fixed = nullptr,
+                      size_t fixed_bytes = 0)
 {
+    const bool may_alloc = fixed == nullptr;
     if (n_blocks <= 0)
         return fail(KLMI_E_ARG, "klmi_bank_render: n_blocks must be positive, got %d", n_blocks);
     TRY(check_external(b, n_blocks));
-    TRY(sync_events(b));
-    TRY(sync_notes(b));
-    TRY(ensure_fx_ring(b));
+    TRY(sync_events(b, may_alloc));
+    TRY(sync_notes(b, may_alloc));
+    TRY(ensure_fx_ring(b, may_alloc));
     if (b->desc.has_reverb)
         return render_reverb(b, n_blocks, dev_mix);
     hipStream_t st = b->ctx->stream;
@@ -1379,33 +1413,55 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix)
     const int rows = groups * kWavesPerGroup;
     const int slices = bus_slices(rows);
     const size_t per_block = (size_t)rows * planes * kBlock * sizeof(float);
-    int bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, ((size_t)256 << 20) / per_block));
-    HIP_TRY(b->partial.reserve((size_t)rows * planes * kBlock * bpl));
-    HIP_TRY(b->stage.reserve((size_t)slices * planes * kBlock * bpl));
+    const size_t stage_per_block = (size_t)slices * planes * kBlock * sizeof(double);
+    int bpl;
+    float *partial;
+    double *stage;
+    if (may_alloc) {
+        bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, ((size_t)256 << 20) / per_block));
+        HIP_TRY(b->partial.reserve((size_t)rows * planes * kBlock * bpl));
+        HIP_TRY(b->stage.reserve((size_t)slices * planes * kBlock * bpl));
+        partial = b->partial.p;
+        stage = b->stage.p;
+    } else {
+        // partial buses first, slice sums behind them: both are whole KiB per block, so the
+        // second part stays 256-byte aligned
+        bpl = (int)std::min<size_t>((size_t)n_blocks, fixed_bytes / (per_block + stage_per_block));
+        if (bpl < 1)
+            return fail(KLMI_E_ARG, "klmi_bank_render_device_noalloc: one buffer of this bank "
+                                    "(%d voices, %d channel(s)) needs %zu bytes of scratch, the "
+                                    "static array holds %zu", b->n, planes,
+                        per_block + stage_per_block, fixed_bytes);
+        partial = reinterpret_cast<float *>(fixed);
+        stage = reinterpret_cast<double *>(fixed + per_block * (size_t)bpl);
+    }
     BankView view = make_view(b);
     b->timed_launches = 0;
     for (int base = 0; base < n_blocks; base += bpl) {
         const int nb = std::min(bpl, n_blocks - base);
-        TRY(timing_begin(b, b->timed_launches));
+        if (may_alloc)
+            TRY(timing_begin(b, b->timed_launches));
         hipError_t e;
         if (b->desc.stereo)
             e = dispatch_voice<OUT_MIX_STEREO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
                                                b->n, base, b->block_clock + (uint32_t)base, nb, 0,
-                                               b->partial.p, nullptr);
+                                               partial, nullptr);
         else
             e = dispatch_voice<OUT_MIX_MONO>(b->desc.has_env, b->desc.has_filter, st, view, 0,
                                              b->n, base, b->block_clock + (uint32_t)base, nb, 0,
-                                             b->partial.p, nullptr);
+                                             partial, nullptr);
         if (e != hipSuccess)
             return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
-        HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
-        b->timed_launches++;
+        if (may_alloc) {
+            HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
+            b->timed_launches++;
+        }
         const size_t bus_len = (size_t)nb * planes * kBlock;
         hipLaunchKernelGGL(bus_slice_kernel, dim3((unsigned)((bus_len + 1023) / 1024), slices),
-                           dim3(256), 0, st, b->partial.p, rows, bus_len, b->stage.p);
+                           dim3(256), 0, st, partial, rows, bus_len, stage);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bus_finish_kernel, dim3((unsigned)((bus_len + 255) / 256)), dim3(256), 0,
-                           st, b->stage.p, slices, bus_len, b->mix_divisor,
+                           st, stage, slices, bus_len, b->mix_divisor,
                            dev_mix + (size_t)base * planes * kBlock);
         HIP_TRY(hipGetLastError());
     }
@@ -1421,6 +1477,21 @@ extern "C" int klmi_bank_render_device(klmi_bank *b, int n_blocks, float *dev_mi
         return fail(KLMI_E_ARG, "klmi_bank_render_device: null argument");
     TRY(use(b->ctx));
     return render_mix(b, n_blocks, dev_mix);
+}
+
+// The same render with the static scratch array as its only workspace: no hipMalloc, hipFree
+// or other allocating call on this path.  The kernels overwrite every partial row and slice
+// sum they later read, so nothing of the previous call's contents has to be cleared.
+extern "C" int klmi_bank_render_device_noalloc(klmi_bank *b, int n_blocks, float *dev_mix)
+{
+    if (!b || !dev_mix)
+        return fail(KLMI_E_ARG, "klmi_bank_render_device_noalloc: null argument");
+    TRY(use(b->ctx));
+    if (b->desc.has_reverb)
+        return fail(KLMI_E_STATE, "klmi_bank_render_device_noalloc: reverb banks stage their dry "
+                                  "bus in buffers that grow with the call; use "
+                                  "klmi_bank_render_device");
+    return render_mix(b, n_blocks, dev_mix, b->ctx->scratch_ptr, kScratchBytes);
 }
 
 extern "C" int klmi_bank_render(klmi_bank *b, int n_blocks, float *host_mix)

@@ -61,7 +61,8 @@ EXPORTS = [
     'klmi_bank_create', 'klmi_bank_destroy', 'klmi_bank_set_params', 'klmi_bank_state_get',
     'klmi_bank_state_set', 'klmi_bank_events', 'klmi_bank_notes',
     'klmi_bank_set_mix_divisor', 'klmi_bank_set_input',
-    'klmi_bank_render', 'klmi_bank_render_device', 'klmi_bank_render_voices',
+    'klmi_bank_render', 'klmi_bank_render_device', 'klmi_bank_render_device_noalloc',
+    'klmi_bank_render_voices',
     'klmi_bank_render_voices_f64', 'klmi_bank_render_voices_device', 'klmi_bank_reverb_state_get',
     'klmi_bank_last_kernel_ms', 'klmi_bounce_cycles', 'klmi_bank_bounce',
     'klmi_bank_bounce_device', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
@@ -131,6 +132,7 @@ def load():
     L.klmi_bank_set_input.argtypes = [_vp, _dp, C.c_int]
     L.klmi_bank_render.argtypes = [_vp, C.c_int, _fp]
     L.klmi_bank_render_device.argtypes = [_vp, C.c_int, _vp]
+    L.klmi_bank_render_device_noalloc.argtypes = [_vp, C.c_int, _vp]
     L.klmi_bank_render_voices.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _fp]
     L.klmi_bank_render_voices_f64.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _dp]
     L.klmi_bank_render_voices_device.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp]
@@ -410,6 +412,10 @@ class Bank:
 
     def render_device(self, n_blocks, dev_ptr):
         _check(load().klmi_bank_render_device(self._h, int(n_blocks), _vp(dev_ptr)))
+
+    def render_device_noalloc(self, n_blocks, dev_ptr):
+        """render_device through the library's static scratch array: allocates nothing."""
+        _check(load().klmi_bank_render_device_noalloc(self._h, int(n_blocks), _vp(dev_ptr)))
 
     def render_voices(self, n_blocks, first=0, count=None, f64=False):
         """Preview of per-voice streams [count][n_blocks*256]; state untouched."""
