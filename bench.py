@@ -6,10 +6,17 @@
 N == 1: BASELINE.json configs[2], the synthetic 65,536-voice polyphonic patch
 (saw Oscillator -> ADSR -> Butterworth-2 lowpass -> Mixer, 44.1 kHz, 256-sample
 blocks), 512 blocks per step.  N > 1 (launched by torch.distributed.run, one
-rank per GPU): every rank renders its own contiguous 65,536-voice shard of the
-N*65,536-voice patch (weak scaling, configs[4] at N == 16 would be the 1M-voice
-patch), the un-normalised per-GPU buses are summed by ONE RCCL reduce per step
-and the root divides by the global voice count (mixer.py:46-47).
+rank per GPU): BASELINE.json configs[4]'s sharding -- every rank renders its own
+contiguous 131,072-voice shard of the N*131,072-voice patch (weak scaling; N == 8
+IS configs[4], the 1,048,576-voice patch), the un-normalised per-GPU buses are
+summed by ONE RCCL reduce per step and the root divides by the global voice
+count (mixer.py:46-47).
+
+At N == 1 the JSON line also carries two sub-records measured in the same run
+(`extra`): config 3 materialised (one float32 stream per voice written to HBM)
+and BASELINE configs[3] (4,096 reverb channels, comb delay lines in HBM), the
+two HBM-bound shapes of the path, each against the 8 TB/s spec and against the
+rate a plain hand-written streaming kernel reaches on this GPU in this run.
 
 A step = one klmi_bank_render_device call over 512 blocks (state resident,
 events pre-uploaded) + the reduce (N > 1) + the D2H copy of the 512 KB bus on
@@ -29,7 +36,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-VOICES_PER_GPU = int(os.environ.get('KLANG_BENCH_VOICES', '65536'))  # override: experiments only
+VOICES_SINGLE = 65536     # configs[2]
+VOICES_SHARD = 131072     # configs[4]: 1,048,576 voices over 8 GPUs
 BLOCKS_PER_STEP = 512
 B = 256
 # params 80 B + 2 x state 36 B per voice per 256-sample block, + 4 B/N bus
@@ -38,6 +46,97 @@ HBM_PEAK_GBS = 8000.  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured cop
 # VALU issue roof: 256 CUs x 4 SIMDs, one 64-lane float64 instruction per 4 cycles at 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.          # wave-instructions/s (= 39.3e12 lane-ops/s / 64)
 VALU_INSTR_PER_VOICE_SAMPLE = 24.2              # SQ_INSTS_VALU per wave-sample (profiles/), fallback
+
+
+def stats(xs):
+    xs = sorted(xs)
+    return {'median': xs[len(xs) // 2] if len(xs) % 2 else .5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]),
+            'min': xs[0], 'max': xs[-1]}
+
+
+def extra_records(ctx, native, patches, torch, log):
+    """The two HBM-bound shapes of the path, measured in this run (N == 1 only)."""
+    out = {}
+    rates = {k: ctx.stream_rate(k, 1 << 30, 10) for k in ('copy', 'update', 'fill')}
+    out['stream_probe_GBs'] = dict(rates, note='plain float4 grid-stride kernels of this library on '
+                                   '1 GiB buffers, bytes read + written (klmi_ctx_stream_rate)')
+    log('stream probe GB/s: %s' % ', '.join('%s %.0f' % kv for kv in rates.items()))
+
+    def timed(bank, n_blocks, fn, runs=5):
+        wall, kern = [], []
+        for _ in range(runs + 1):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            ctx.synchronize()
+            wall.append(time.perf_counter() - t0)
+            kern.append(bank.last_kernel_ms()[0])
+        return wall[1:], kern[1:], bank.last_kernel_ms()[1]
+
+    def no_events(patch):
+        p = patches.Patch(patch)
+        p['events'] = patch.events[:0]
+        return p
+
+    def queue(bank, ev, n_blocks, runs):
+        allev = []
+        for r in range(runs):
+            e = ev.copy()
+            e['block'] += r * n_blocks
+            allev.append(e)
+        bank.events(np.concatenate(allev))
+
+    # -- config 3 materialised: A3m = 4.594 B per voice-sample (SURVEY 8d)
+    n, nb = 65536, 256
+    patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=10, off_span=20)
+    bank = native.Bank(ctx, n, has_env=True, has_filter=True)
+    bank.load_patch(patch)
+    buf = torch.empty((n, nb * B), dtype=torch.float32, device='cuda')
+    wall, kern, launches = timed(bank, nb, lambda: bank.render_voices_device(nb, buf.data_ptr()))
+    units, ms = n * nb * B, stats(kern)['median']
+    gbs = units * 4.594 / (ms * 1e-3) / 1e9
+    out['materialised'] = {
+        'workload': 'config 3 materialised: 65,536 voices x %d blocks, one float32 stream per '
+                    'voice written to HBM (klmi_bank_render_voices_device)' % nb,
+        'value': units / (ms * 1e-3), 'unit': 'voice-samples/s', 'kernel_ms': stats(kern),
+        'wall_ms': stats([w * 1e3 for w in wall]),
+        'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': gbs / HBM_PEAK_GBS, 'frac_of_probe_fill': gbs / rates['fill'],
+                     'algorithmic_bytes_per_voice_sample': 4.594,
+                     'kernel': 'voice_kernel<env,biquad,voices_f32>'}}
+    del buf
+    bank.close()
+    log('materialised: %.3g voice-samples/s, %.0f GB/s' % (units / (ms * 1e-3), gbs))
+
+    # -- BASELINE configs[3]: 4,096 reverb channels, delay lines in HBM
+    n, nb = 4096, 512
+    patch = patches.reverb_patch(n_channels=n, n_blocks=nb)
+    for rings, per_sample in (('f32', 88.), ('f64', 168.)):
+        patch['reverb'] = dict(patch['reverb'], rings=rings)
+        bank = native.Bank(ctx, n, has_env=True, has_reverb=True, reverb=patch['reverb'])
+        bank.load_patch(no_events(patch))
+        queue(bank, patch.events, nb, 6)
+        bus = torch.empty((nb, 1, B), dtype=torch.float32, device='cuda')
+        wall, kern, launches = timed(bank, nb, lambda: bank.render_device(nb, bus.data_ptr()))
+        units = n * nb * B
+        ms, wall_ms = stats(kern)['median'], stats([w * 1e3 for w in wall])
+        gbs = units * per_sample / (ms * 1e-3) / 1e9
+        whole = units * per_sample / (wall_ms['median'] * 1e-3) / 1e9
+        out['config4_rings_' + rings] = {
+            'workload': 'configs[3]: %d channels Voice(sine, AR(.01,1.)) -> Reverb(decay 3, dryWet .7) '
+                        '-> Mixer, %d blocks, %s ring storage (%.2f GB of delay lines)'
+                        % (n, nb, rings, n * 13896 * (4 if rings == 'f32' else 8) / 1e9),
+            'value': units / (wall_ms['median'] * 1e-3), 'unit': 'channel-samples/s',
+            'reverb_kernel_ms': stats(kern), 'reverb_launches': launches, 'wall_ms': wall_ms,
+            'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': gbs / HBM_PEAK_GBS, 'whole_call_frac': whole / HBM_PEAK_GBS,
+                         'frac_of_probe_update': gbs / rates['update'],
+                         'algorithmic_bytes_per_channel_sample': per_sample,
+                         'kernel': 'reverb_kernel'}}
+        bank.close()
+        log('config4 %s rings: %.3g channel-samples/s, kernel %.0f GB/s' %
+            (rings, units / (wall_ms['median'] * 1e-3), gbs))
+    return out
 
 
 def cpu_baseline(n_voices, log):
@@ -74,6 +173,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the sub-records (N == 1)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -117,6 +217,9 @@ def main():
     elif world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
+    # N == 1 is configs[2]; N > 1 shards like configs[4] (override: experiments only)
+    VOICES_PER_GPU = int(os.environ.get('KLANG_BENCH_VOICES',
+                                        VOICES_SINGLE if world == 1 else VOICES_SHARD))
     n_total = VOICES_PER_GPU * world
     steps_total = args.warmup + args.steps
     stream = torch.cuda.current_stream()
@@ -150,17 +253,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, launches = [], 0
+    kernel_ms, step_ms, launches = [], [], 0
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
         # HIP-event durations of this step's voice-kernel launches (same stream);
         # reading them waits for the step, which the next step depends on anyway
         ms, launches = bank.last_kernel_ms()
         kernel_ms.append(ms)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     fence()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -175,26 +280,36 @@ def main():
         value = units / elapsed
         per_launch_units = VOICES_PER_GPU * BLOCKS_PER_STEP * B / max(launches, 1)
         avg_launch_s = (sum(kernel_ms) / len(kernel_ms)) / max(launches, 1) * 1e-3
+        median_launch_s = stats(kernel_ms)['median'] / max(launches, 1) * 1e-3
         achieved = ALGO_BYTES_PER_VOICE_SAMPLE * per_launch_units / avg_launch_s / 1e9
-        traffic, valu_instr = None, VALU_INSTR_PER_VOICE_SAMPLE
+        # PMC counters cannot be read from inside this process: traffic and the instruction
+        # count are STATIC figures from the committed rocprofv3 passes over this same command
+        # (tools/profile_bench.sh), used only when they were taken at this launch size
+        traffic, valu_instr, counters_from = None, VALU_INSTR_PER_VOICE_SAMPLE, None
         tfile = os.path.join(ROOT, 'profiles', 'traffic_voice_kernel.json')
         if os.path.exists(tfile):
             with open(tfile) as fh:
                 prof = json.load(fh)
-            # PMC results of tools/profile_bench.sh for this same workload (per launch)
             if prof.get('voice_samples_per_launch') == per_launch_units:
                 traffic = prof.get('hbm_bytes_per_launch')
                 valu_instr = prof.get('valu_instructions_per_voice_sample', valu_instr)
+                counters_from = 'profiles/traffic_voice_kernel.json (static: rocprofv3 --pmc ' \
+                                'passes over this command, %s)' % prof.get('round', 'earlier round')
         result = {
             'metric': 'voice-samples/sec (osc+ADSR+biquad)', 'value': value,
             'unit': 'voice-samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'ms_per_step_spread': stats(step_ms),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {
-                'workload': 'synthetic %d-voice polyphonic patch (saw Oscillator -> ADSR -> '
+                'workload': 'synthetic %s-voice polyphonic patch (saw Oscillator -> ADSR -> '
                             'Butterworth-2 lowpass -> Mixer), 44.1 kHz, 256-sample blocks, '
-                            '%d blocks/step, fused mix-down' % (n_total, BLOCKS_PER_STEP),
+                            '%d blocks/step, fused mix-down%s'
+                            % (format(n_total, ','), BLOCKS_PER_STEP,
+                               '' if world == 1 else ', sharded %s voices per GPU across %d GPUs%s'
+                               % (format(VOICES_PER_GPU, ','), world,
+                                  ' (BASELINE configs[4])' if n_total == 1048576 else '')),
                 'voices_per_gpu': VOICES_PER_GPU, 'blocks_per_step': BLOCKS_PER_STEP,
                 'parallelism': 'voice shards x%d, one RCCL reduce of the mix bus per step' % world
                                if world > 1 else 'single GPU',
@@ -204,7 +319,9 @@ def main():
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                 'kernel': 'voice_kernel<env,biquad,mix_mono>', 'launches_per_step': launches,
-                'avg_launch_ms': avg_launch_s * 1e3,
+                'avg_launch_ms': avg_launch_s * 1e3, 'median_launch_ms': median_launch_s * 1e3,
+                'launch_ms_spread': stats([k / max(launches, 1) for k in kernel_ms]),
+                'traffic_source': counters_from,
                 'algorithmic_bytes_per_voice_sample': ALGO_BYTES_PER_VOICE_SAMPLE,
                 'note': 'fused path is float64-VALU-issue bound, not HBM bound (SURVEY 8d): state '
                         'stays in registers for the whole launch, so measured traffic is below the '
@@ -216,6 +333,8 @@ def main():
                 'valu_frac': (per_launch_units / avg_launch_s) / 64. * valu_instr / VALU_ISSUE_PEAK,
             },
         }
+        if world == 1 and not args.no_extra:
+            result['extra'] = extra_records(ctx, native, patches, torch, log)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(VOICES_PER_GPU, log)
         print(json.dumps(result), flush=True)

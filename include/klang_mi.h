@@ -142,8 +142,8 @@ typedef enum {
                                k2 smoothness, k3 dutyCycle; state k0 lfo phase, k1 zi */
     KLMI_FX_DELAY = 7,      /* Delay (effects.py:136-174): k0 time (s, <= 2; at least one
                                buffer: 256 samples), k1 feedback, k2 drywet; state k0 ring
-                               position.  Setting k0 (of any voice) empties every delay line
-                               of the bank at the next render. */
+                               position.  Setting k0 empties the lines of those voices whose
+                               length in samples changed; the others keep their contents. */
     KLMI_FX_SUBSAMPLE = 8,  /* Subsampler (effects.py:388-417): k0 factor, a power of 2 in 2..128 */
     KLMI_FX_BITCRUSH = 9,   /* Bitcrusher (effects.py:420-449): k0 nBits in 0..15; samples go
                                through int16 like convert_samples_to_int (wavfile.py:23-30) */
@@ -195,6 +195,11 @@ typedef struct {
                                  are addressed to instruments with klmi_bank_notes and routed
                                  on the device (synthesizer.py:200-209).  Implies gated; the
                                  default mix divisor is P (synthesizer.py:219) */
+    int32_t reverb_rings_f32; /* storage of the Reverb's delay lines: 0 float64 as in
+                                 _filters.c:33 (168 B of HBM traffic per channel-sample with
+                                 10 combs), 1 float32 (88 B; the comb arithmetic stays float64,
+                                 each ring write is rounded once) */
+    int32_t reserved;
 } klmi_chain_desc;
 
 /* Block-boundary events, the batched form of Voice.process_incoming_notes
@@ -243,6 +248,14 @@ const char *klmi_version(void);
 int klmi_ctx_create(int device, void *stream, klmi_ctx **out);
 int klmi_ctx_destroy(klmi_ctx *ctx);
 int klmi_ctx_synchronize(klmi_ctx *ctx);
+
+/* Measurement aid (no reference counterpart): the rate this GPU's memory system gives a
+ * plain hand-written streaming kernel -- 16 bytes per lane and access, grid-stride -- over
+ * `bytes` per buffer, `reps` timed launches (HIP events on the context's stream).  kind 0
+ * copy (read + write), 1 in-place update (read-modify-write, the Reverb kernel's access
+ * mix), 2 fill (write only), 3 sum (read only).  gb_per_s counts bytes read + written.
+ * bench.py quotes the HBM-bound kernels against it ("achievable") next to the 8 TB/s spec. */
+int klmi_ctx_stream_rate(klmi_ctx *ctx, int kind, size_t bytes, int reps, double *gb_per_s);
 
 /* Host-side design helpers (no GPU work).
  * effects.py:260-269: the 1000-point log2 grid and scipy.signal.butter(N=2,

@@ -312,6 +312,58 @@ extern "C" int klmi_ctx_synchronize(klmi_ctx *ctx)
     return 0;
 }
 
+// What the memory system of this GPU gives a plain streaming kernel (bus_kernels.h):
+// `reps` launches over `bytes` per buffer, timed with HIP events on the context's stream.
+extern "C" int klmi_ctx_stream_rate(klmi_ctx *ctx, int kind, size_t bytes, int reps,
+                                    double *gb_per_s)
+{
+    TRY(use(ctx));
+    if (kind < 0 || kind > 3 || bytes < 4096 || reps < 1 || !gb_per_s)
+        return fail(KLMI_E_ARG, "klmi_ctx_stream_rate: kind 0..3, bytes >= 4096, reps >= 1");
+    const size_t n4 = bytes / sizeof(float4);
+    DevBuf<float4> a, b;
+    hipError_t e = a.alloc(n4);
+    if (e == hipSuccess && kind == 0)
+        e = b.alloc(n4);
+    if (e != hipSuccess)
+        return fail(KLMI_E_MEMORY, "klmi_ctx_stream_rate: %s", hipGetErrorString(e));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(a.p, 0, n4 * sizeof(float4), st));
+    if (b.p)
+        HIP_TRY(hipMemsetAsync(b.p, 0, n4 * sizeof(float4), st));
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    const dim3 grid((unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)ctx->n_cus * 32)), block(256);
+    auto launch = [&] {
+        const float4 *src = kind == 0 ? b.p : a.p;
+        switch (kind) {
+        case 0: hipLaunchKernelGGL(stream_probe_kernel<0>, grid, block, 0, st, src, a.p, n4, 1.f); break;
+        case 1: hipLaunchKernelGGL(stream_probe_kernel<1>, grid, block, 0, st, src, a.p, n4, 1.f); break;
+        case 2: hipLaunchKernelGGL(stream_probe_kernel<2>, grid, block, 0, st, src, a.p, n4, 1.f); break;
+        default: hipLaunchKernelGGL(stream_probe_kernel<3>, grid, block, 0, st, src, a.p, n4, 1.f); break;
+        }
+    };
+    launch();   // warm-up
+    (void)hipEventRecord(t0, st);
+    for (int r = 0; r < reps; ++r)
+        launch();
+    (void)hipEventRecord(t1, st);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipEventSynchronize(t1);
+    float ms = 0.f;
+    if (e == hipSuccess)
+        e = hipEventElapsedTime(&ms, t0, t1);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (e != hipSuccess)
+        return fail(KLMI_E_DEVICE, "klmi_ctx_stream_rate: %s", hipGetErrorString(e));
+    const double moved = (double)(n4 * sizeof(float4)) * (kind <= 1 ? 2. : 1.) * reps;
+    *gb_per_s = moved / ((double)ms * 1e-3) / 1e9;
+    return 0;
+}
+
 extern "C" int klmi_filter_grid(double *freqs)
 {
     if (!freqs)
@@ -322,12 +374,13 @@ extern "C" int klmi_filter_grid(double *freqs)
 
 extern "C" int klmi_filter_grid_index(double frequency)
 {
-    static std::vector<double> grid;
-    if (grid.empty()) {
+    // built once, by whichever thread comes first (initialisation of a function-local
+    // static is synchronised by the language)
+    static const std::vector<double> grid = [] {
         std::vector<double> g(KLMI_GRID_POINTS);
         make_grid(g.data());
-        grid.swap(g);
-    }
+        return g;
+    }();
     return grid_index(grid.data(), frequency);
 }
 
@@ -409,6 +462,8 @@ struct klmi_bank {
     // host shadows of the parameters the device arrays are derived from
     std::vector<double> attack, decay, sustain, release, overshoot, gain, pan;
     std::vector<uint8_t> loop, retrigger;
+    std::vector<uint8_t> is_external;   // wave id == KLMI_WAVE_EXTERNAL, per voice
+    int n_external = 0;                 // how many of them: only then is the input span checked
 
     // device parameters
     DevBuf<double> duty, env_coef, gain_l, gain_r;
@@ -419,7 +474,8 @@ struct klmi_bank {
     // host, what the kernel needs [8][kFxSlots][n] on the device, the delay stage's rings
     std::vector<double> fx_raw;
     DevBuf<double> fx_par, fx_ring, fx_ring_backup;
-    int fx_ring_cap = 0;                 // longest line of the bank; 0 = not allocated yet
+    int fx_ring_cap = 0;                 // longest line the allocation holds; 0 = not allocated yet
+    bool fx_ring_dirty = true;           // a delay time was set since the lines were last sized
     int fx_ring_stride = 0;              // doubles per voice row: capacity + 8 mirror slots,
                                          // rounded up to whole 128-byte lines
     int fx_delay_stage = -1;
@@ -465,7 +521,8 @@ struct klmi_bank {
     ReverbState reverb;
     std::vector<int32_t> taps;
     std::vector<double> alphas;
-    DevBuf<double> rings, d_alphas;
+    DevBuf<double> rings, d_alphas;      // float64 delay lines (desc.reverb_rings_f32 == 0)
+    DevBuf<float> rings32;               // float32 storage of the same lines
     DevBuf<int32_t> d_taps, d_ring_offset;
     std::vector<int32_t> ring_pos;  // host-tracked, identical for every voice
     DevBuf<float> rv_partial;
@@ -633,33 +690,75 @@ static int upload_fx(klmi_bank *b, int stage, int first, int count)
 }
 
 // The delay stage's lines [n][stride], stride >= the longest line of the bank + 8 mirror
-// slots; (re)allocated zeroed when the capacity changed (ring_buffer.py:42 zero-initialised).
+// slots, zero-initialised (ring_buffer.py:42).  Sized when a delay time was set since the last
+// render; an allocation that is too short grows and keeps what the lines hold.
 static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
 {
-    if (b->fx_delay_stage < 0)
+    if (b->fx_delay_stage < 0 || !b->fx_ring_dirty)
         return 0;
     const size_t n = (size_t)b->n;
-    int cap = 0;
+    int need = 0;
     for (size_t v = 0; v < n; ++v)
-        cap = std::max(cap, (int)(b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + v] *
-                                  KLMI_SAMPLING_RATE));
-    if (cap == b->fx_ring_cap)
+        need = std::max(need, (int)(b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + v] *
+                                    KLMI_SAMPLING_RATE));
+    if (need <= b->fx_ring_cap) {
+        b->fx_ring_dirty = false;
         return 0;
+    }
     if (!may_alloc)
-        return fail(KLMI_E_STATE, "the Delay stage's lines are not allocated yet (or their length "
-                                  "changed): one allocating render (or preview) must come first");
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    b->fx_ring.release();
-    b->fx_ring_backup.release();
-    const int stride = (cap + 8 + 15) & ~15;
-    hipError_t e = b->fx_ring.alloc((size_t)stride * n);
+        return fail(KLMI_E_STATE, "the Delay stage's lines are not allocated yet (or a longer "
+                                  "time was set): one allocating render (or preview) must come first");
+    hipStream_t st = b->ctx->stream;
+    const int stride = (need + 8 + 15) & ~15;
+    DevBuf<double> grown;
+    hipError_t e = grown.alloc((size_t)stride * n);
     if (e != hipSuccess)
-        return fail(KLMI_E_MEMORY, "delay lines (%d samples x %d voices) do not fit: %s", cap, b->n,
+        return fail(KLMI_E_MEMORY, "delay lines (%d samples x %d voices) do not fit: %s", need, b->n,
                     hipGetErrorString(e));
-    HIP_TRY(hipMemset(b->fx_ring.p, 0, sizeof(double) * (size_t)stride * n));
+    // ordered on the context's stream like the kernels that read the lines (a caller's
+    // non-blocking stream is not ordered after the null stream)
+    HIP_TRY(hipMemsetAsync(grown.p, 0, sizeof(double) * (size_t)stride * n, st));
+    if (b->fx_ring_cap > 0) {
+        HIP_TRY(hipMemcpy2DAsync(grown.p, sizeof(double) * stride, b->fx_ring.p,
+                                 sizeof(double) * b->fx_ring_stride,
+                                 sizeof(double) * b->fx_ring_stride, n, hipMemcpyDeviceToDevice, st));
+    } else {
+        HIP_TRY(hipMemsetAsync(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage), 0, sizeof(double) * n, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));   // the old lines are freed below
+    std::swap(b->fx_ring.p, grown.p);
+    std::swap(b->fx_ring.n, grown.n);
+    b->fx_ring_backup.release();
     b->fx_ring_stride = stride;
-    HIP_TRY(hipMemset(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage), 0, sizeof(double) * n));
-    b->fx_ring_cap = cap;
+    b->fx_ring_cap = need;
+    b->fx_ring_dirty = false;
+    return 0;
+}
+
+// New delay times for voices [first, first+count): a voice whose line length (in samples)
+// changed starts again with an empty line at position 0; the others keep theirs.
+static int reset_changed_delay_lines(klmi_bank *b, int first, int count, const double *new_time)
+{
+    const size_t n = (size_t)b->n;
+    const double *old_time = &b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + first];
+    hipStream_t st = b->ctx->stream;
+    int run = -1;   // start of the current run of changed voices
+    for (int i = 0; i <= count; ++i) {
+        const bool changed = i < count && (int)(old_time[i] * KLMI_SAMPLING_RATE) !=
+                                              (int)(new_time[i] * KLMI_SAMPLING_RATE);
+        if (changed && run < 0)
+            run = i;
+        if (!changed && run >= 0) {
+            if (b->fx_ring_cap > 0) {
+                HIP_TRY(hipMemsetAsync(b->fx_ring.p + (size_t)(first + run) * b->fx_ring_stride, 0,
+                                       sizeof(double) * (size_t)(i - run) * b->fx_ring_stride, st));
+                HIP_TRY(hipMemsetAsync(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage) + first + run, 0,
+                                       sizeof(double) * (size_t)(i - run), st));
+            }
+            b->fx_ring_dirty = true;
+            run = -1;
+        }
+    }
     return 0;
 }
 
@@ -724,6 +823,7 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
     b->pan.assign(n, 0.);   // panning.py:20
     b->loop.assign(n, 0);
     b->retrigger.assign(n, 0);
+    b->is_external.assign(n, 0);
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) {
@@ -823,6 +923,10 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         step(upload_gains(b, 0, n_voices));
     if (rc == 0 && desc->has_reverb)
         step(bank_init_reverb(b));
+    // the fills above went through the null stream: finished before a caller's
+    // non-blocking stream sees the bank
+    if (rc == 0 && hipDeviceSynchronize() != hipSuccess)
+        step(fail(KLMI_E_DEVICE, "klmi_bank_create: device synchronisation failed"));
     if (rc != 0) {
         delete b;
         return rc;
@@ -944,10 +1048,10 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
                     return fail(KLMI_E_ARG, "klmi_bank_set_params: RingModulator Lfo wave id %g "
                                             "(sine, square, sawtooth, triangle are 0..3)", host[i]);
         }
+        if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0)
+            TRY(reset_changed_delay_lines(b, first, count, host));
         std::copy(host, host + count,
                   b->fx_raw.begin() + ((size_t)stage * KLMI_FX_PARAMS + k) * b->n + first);
-        if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0)
-            b->fx_ring_cap = 0;  // new lengths: the lines (and their mirror slots) start empty
         return upload_fx(b, stage, first, count);
     }
     switch (field) {
@@ -970,6 +1074,11 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
             if (!(host[i] >= 0. && host[i] <= (double)KLMI_WAVE_EXTERNAL))
                 return fail(KLMI_E_ARG, "klmi_bank_set_params: unknown wave id %g", host[i]);
             w[i] = (int32_t)host[i];
+        }
+        for (int i = 0; i < count; ++i) {
+            const uint8_t ext = w[i] == KLMI_WAVE_EXTERNAL;
+            b->n_external += (int)ext - (int)b->is_external[first + i];
+            b->is_external[first + i] = ext;
         }
         HIP_TRY(hipMemcpyAsync(b->wave.p + first, w.data(), sizeof(int32_t) * count,
                                hipMemcpyHostToDevice, st));
@@ -1362,17 +1471,18 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
 
 static int check_external(klmi_bank *b, int n_blocks)
 {
-    // W_EXTERNAL voices read ext_input; make sure it covers the span
+    // W_EXTERNAL voices read ext_input: it has to cover the span.  The bank counts such
+    // voices on the host (klmi_bank_set_params, KLMI_F_WAVE), so ordinary banks pay nothing.
+    if (b->n_external == 0)
+        return 0;
     if (b->ext_input.p == nullptr || b->ext_blocks - b->ext_cursor < n_blocks) {
-        // only an error if some voice actually is external; the bank tracks that on set_params
-        std::vector<int32_t> w(b->n);
-        HIP_TRY(hipMemcpy(w.data(), b->wave.p, sizeof(int32_t) * b->n, hipMemcpyDeviceToHost));
-        for (int v = 0; v < b->n; ++v)
-            if (w[v] == W_EXTERNAL)
-                return fail(KLMI_E_STATE,
-                            "voice %d uses KLMI_WAVE_EXTERNAL but only %d blocks of external "
-                            "input are left, %d needed", v, b->ext_blocks - b->ext_cursor,
-                            n_blocks);
+        int v = 0;
+        while (v < b->n && !b->is_external[v])
+            ++v;
+        return fail(KLMI_E_STATE,
+                    "voice %d uses KLMI_WAVE_EXTERNAL but only %d blocks of external input are "
+                    "left, %d needed", v, b->ext_input.p ? b->ext_blocks - b->ext_cursor : 0,
+                    n_blocks);
     }
     return 0;
 }
@@ -1764,12 +1874,15 @@ static int bank_init_reverb(klmi_bank *b)
     }
     r.min_length = min_tap;
     b->ring_pos.assign(r.n_echos, 0);
-    hipError_t e = b->rings.alloc(total * (size_t)b->n);
+    const bool f32 = d.reverb_rings_f32 != 0;
+    hipError_t e = f32 ? b->rings32.alloc(total * (size_t)b->n) : b->rings.alloc(total * (size_t)b->n);
     if (e != hipSuccess)
         return fail(KLMI_E_MEMORY, "Reverb: could not allocate %zu ring samples: %s",
                     total * (size_t)b->n, hipGetErrorString(e));
-    HIP_TRY(hipMemset(b->rings.p, 0, sizeof(double) * total * (size_t)b->n));  // _filters.c:57
-    r.rings = b->rings.p;
+    r.rings = f32 ? (void *)b->rings32.p : (void *)b->rings.p;
+    // _filters.c:57 zero-initialised; ordered on the context's stream like the kernels
+    HIP_TRY(hipMemsetAsync(r.rings, 0, (f32 ? sizeof(float) : sizeof(double)) * total * (size_t)b->n,
+                           b->ctx->stream));
     return 0;
 }
 
@@ -1791,12 +1904,36 @@ static int reverb_streams(klmi_bank *b)
 // the reverb kernels of chunk j (HBM bound) run on the context's stream; two dry
 // buses alternate.  Order is carried by events only: ready[i] (dry bus i written),
 // done[i] (reverb finished reading dry bus i).
+template <int SPW>
+static void launch_reverb(bool f32, bool stereo, dim3 grid, hipStream_t st, const ReverbState &r,
+                          const double *x, int ns, const double *gl, const double *gr,
+                          float *partial, size_t stride)
+{
+    if (f32) {
+        if (stereo)
+            hipLaunchKernelGGL((reverb_kernel<SPW, float, true>), grid, dim3(64), 0, st, r, x, ns, gl,
+                               gr, partial, stride);
+        else
+            hipLaunchKernelGGL((reverb_kernel<SPW, float, false>), grid, dim3(64), 0, st, r, x, ns, gl,
+                               gr, partial, stride);
+    } else {
+        if (stereo)
+            hipLaunchKernelGGL((reverb_kernel<SPW, double, true>), grid, dim3(64), 0, st, r, x, ns, gl,
+                               gr, partial, stride);
+        else
+            hipLaunchKernelGGL((reverb_kernel<SPW, double, false>), grid, dim3(64), 0, st, r, x, ns, gl,
+                               gr, partial, stride);
+    }
+}
+
 static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
 {
     TRY(reverb_streams(b));
     hipStream_t st = b->ctx->stream, aux = b->aux_stream;
     ReverbState &r = b->reverb;
     const size_t n = (size_t)b->n;
+    const bool stereo = b->desc.stereo != 0, f32 = b->desc.reverb_rings_f32 != 0;
+    const int planes = stereo ? 2 : 1;
     // time slab: as many samples as are independent of each other (< shortest ring),
     // whole blocks when possible
     int slab = std::min(r.min_length, 1024);
@@ -1808,18 +1945,24 @@ static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
     HIP_TRY(b->bus_f64.reserve(2 * bus_elems));
     const int wave_groups = (b->n + 63) / 64;
     const size_t partial_stride = (size_t)chunk_blocks * kBlock;
-    HIP_TRY(b->rv_partial.reserve(2 * (size_t)wave_groups * partial_stride));
+    const size_t partial_elems = (size_t)wave_groups * planes * partial_stride;
+    HIP_TRY(b->rv_partial.reserve(2 * partial_elems));
     BankView view = make_view(b);
     b->timed_launches = 0;
     // the side stream starts after everything already queued on the main stream
     HIP_TRY(hipEventRecord(b->rv_start, st));
     HIP_TRY(hipStreamWaitEvent(aux, b->rv_start, 0));
+    static const int spw = [] {
+        const char *e = getenv("KLMI_REVERB_SPW");   // tuning knob, default 4
+        const int v = e ? atoi(e) : kReverbSamplesPerWave;
+        return (v == 2 || v == 8) ? v : 4;
+    }();
     int chunk = 0;
     for (int base = 0; base < n_blocks; base += chunk_blocks, ++chunk) {
         const int nb = std::min(chunk_blocks, n_blocks - base);
         const int buf = chunk & 1;
         double *bus = b->bus_f64.p + (size_t)buf * bus_elems;
-        float *partial = b->rv_partial.p + (size_t)buf * wave_groups * partial_stride;
+        float *partial = b->rv_partial.p + (size_t)buf * partial_elems;
         // 1) dry voices for nb blocks -> bus[sample][voice], on the side stream
         if (chunk >= 2)
             HIP_TRY(hipStreamWaitEvent(aux, b->rv_done[buf], 0));
@@ -1837,21 +1980,17 @@ static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
             for (int k = 0; k < r.n_echos; ++k)
                 r.position[k] = b->ring_pos[k];
             TRY(timing_begin(b, b->timed_launches));
-            static const int spw = [] {
-                const char *e = getenv("KLMI_REVERB_SPW");   // tuning knob, default 4
-                const int v = e ? atoi(e) : kReverbSamplesPerWave;
-                return (v == 2 || v == 8) ? v : 4;
-            }();
             const dim3 grid((unsigned)wave_groups, (unsigned)((ns + spw - 1) / spw));
+            const double *x = bus + (size_t)s0 * n;
             if (spw == 2)
-                hipLaunchKernelGGL(reverb_kernel<2>, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n,
-                                   ns, b->gain_l.p, partial + (size_t)s0, partial_stride);
+                launch_reverb<2>(f32, stereo, grid, st, r, x, ns, b->gain_l.p, b->gain_r.p,
+                                 partial + (size_t)s0, partial_stride);
             else if (spw == 8)
-                hipLaunchKernelGGL(reverb_kernel<8>, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n,
-                                   ns, b->gain_l.p, partial + (size_t)s0, partial_stride);
+                launch_reverb<8>(f32, stereo, grid, st, r, x, ns, b->gain_l.p, b->gain_r.p,
+                                 partial + (size_t)s0, partial_stride);
             else
-                hipLaunchKernelGGL(reverb_kernel<4>, grid, dim3(64), 0, st, r, bus + (size_t)s0 * n,
-                                   ns, b->gain_l.p, partial + (size_t)s0, partial_stride);
+                launch_reverb<4>(f32, stereo, grid, st, r, x, ns, b->gain_l.p, b->gain_r.p,
+                                 partial + (size_t)s0, partial_stride);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
             b->timed_launches++;
@@ -1861,8 +2000,8 @@ static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
         HIP_TRY(hipEventRecord(b->rv_done[buf], st));
         const size_t bus_len = (size_t)total;
         hipLaunchKernelGGL(bus_reduce_strided_kernel, dim3((unsigned)((bus_len + 255) / 256)),
-                           dim3(256), 0, st, partial, wave_groups, partial_stride, bus_len,
-                           b->mix_divisor, dev_mix + (size_t)base * kBlock);
+                           dim3(256), 0, st, partial, wave_groups, planes, partial_stride, bus_len,
+                           b->mix_divisor, dev_mix + (size_t)base * planes * kBlock);
         HIP_TRY(hipGetLastError());
     }
     b->block_clock += (uint32_t)n_blocks;
@@ -1886,8 +2025,15 @@ extern "C" int klmi_bank_reverb_state_get(klmi_bank *b, int voice, double *rings
     for (int t : b->taps)
         total += (size_t)t;
     // rings are [slot][voice]: strided gather of one voice
-    HIP_TRY(hipMemcpy2D(rings, sizeof(double), b->rings.p + voice, sizeof(double) * b->n,
-                        sizeof(double), total, hipMemcpyDeviceToHost));
+    if (b->desc.reverb_rings_f32) {
+        std::vector<float> tmp(total);
+        HIP_TRY(hipMemcpy2D(tmp.data(), sizeof(float), b->rings32.p + voice, sizeof(float) * b->n,
+                            sizeof(float), total, hipMemcpyDeviceToHost));
+        std::copy(tmp.begin(), tmp.end(), rings);
+    } else {
+        HIP_TRY(hipMemcpy2D(rings, sizeof(double), b->rings.p + voice, sizeof(double) * b->n,
+                            sizeof(double), total, hipMemcpyDeviceToHost));
+    }
     for (size_t k = 0; k < b->taps.size(); ++k)
         positions[k] = b->ring_pos[k];
     return 0;

@@ -5,7 +5,27 @@
 #pragma once
 #include "bank_kernels.h"
 
+#include <atomic>
+
 namespace klmi {
+
+// The voice kernels take more than 64 KiB of dynamic LDS, which has to be allowed per
+// kernel and device.  `done` holds one bit per device id below 64 (set after the first
+// success; racing threads at worst set the attribute twice); higher ids set it on every launch.
+inline hipError_t allow_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    const uint64_t bit = dev >= 0 && dev < 64 ? (uint64_t)1 << dev : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit))
+        return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && bit)
+        done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // t[n] = DT * n into the unit's own constant table (kTimeSlots doubles)
 hipError_t upload_time_table_voice(const double *t);

@@ -13,18 +13,12 @@ static hipError_t launch(hipStream_t st, const BankView &view, int first, int co
                          uint32_t clock_base, int n_blocks, int span_total, float *partial,
                          void *out)
 {
-    static bool configured[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    static std::atomic<uint64_t> configured{0};   // per instantiation
     const size_t smem = tile_bytes<MODE>();
     auto kernel = voice_kernel<ENV, FILT, MODE, GATED>;
-    if (dev < 16 && !configured[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess)
-            return e;
-        configured[dev] = true;
-    }
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), smem, configured);
+    if (e != hipSuccess)
+        return e;
     const int groups = (count + kGroup - 1) / kGroup;
     hipLaunchKernelGGL(kernel, dim3(groups), dim3(kGroup), smem, st, view, first, count,
                        block_base, clock_base, n_blocks, span_total, partial, out);

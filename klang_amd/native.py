@@ -56,7 +56,7 @@ NOTE_DTYPE = np.dtype([('instrument', '<u4'), ('block', '<u4'), ('pitch', '<i4')
 
 EXPORTS = [
     'klmi_last_error', 'klmi_version', 'klmi_ctx_create', 'klmi_ctx_destroy',
-    'klmi_ctx_synchronize', 'klmi_filter_grid', 'klmi_filter_grid_index', 'klmi_butter2_lowpass',
+    'klmi_ctx_synchronize', 'klmi_ctx_stream_rate', 'klmi_filter_grid', 'klmi_filter_grid_index', 'klmi_butter2_lowpass',
     'klmi_envelope_coefficients', 'klmi_low_pass_coefficients', 'klmi_panning_amplitudes', 'klmi_reverb_design',
     'klmi_bank_create', 'klmi_bank_destroy', 'klmi_bank_set_params', 'klmi_bank_state_get',
     'klmi_bank_state_set', 'klmi_bank_events', 'klmi_bank_notes',
@@ -82,7 +82,8 @@ class ChainDesc(C.Structure):
                 ('reverb_pre_delay', C.c_double), ('reverb_dry_wet', C.c_double),
                 ('reverb_n_echos', C.c_int32), ('cutoff_lfo', C.c_int32),
                 ('mod_target', C.c_int32), ('n_fx', C.c_int32), ('fx', C.c_uint8 * 8),
-                ('gated', C.c_int32), ('poly_voices', C.c_int32)]
+                ('gated', C.c_int32), ('poly_voices', C.c_int32),
+                ('reverb_rings_f32', C.c_int32), ('reserved', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -114,6 +115,7 @@ def load():
     L.klmi_ctx_create.argtypes = [C.c_int, _vp, C.POINTER(_vp)]
     L.klmi_ctx_destroy.argtypes = [_vp]
     L.klmi_ctx_synchronize.argtypes = [_vp]
+    L.klmi_ctx_stream_rate.argtypes = [_vp, C.c_int, C.c_size_t, C.c_int, _dp]
     L.klmi_filter_grid.argtypes = [_dp]
     L.klmi_filter_grid_index.argtypes = [C.c_double]
     L.klmi_butter2_lowpass.argtypes = [C.c_double, _dp, _dp]
@@ -276,6 +278,14 @@ class Context:
     def synchronize(self):
         _check(load().klmi_ctx_synchronize(self._h))
 
+    def stream_rate(self, kind, n_bytes=1 << 30, reps=10):
+        """GB/s of a plain streaming kernel on this GPU: kind 'copy', 'update' (in-place
+        read-modify-write), 'fill' or 'sum' (klmi_ctx_stream_rate)."""
+        out = C.c_double()
+        _check(load().klmi_ctx_stream_rate(self._h, ('copy', 'update', 'fill', 'sum').index(kind),
+                                           int(n_bytes), int(reps), C.byref(out)))
+        return out.value
+
     def close(self):
         """Destroys the context after closing every object created on it."""
         if self._h:
@@ -318,7 +328,8 @@ class Bank:
                               float(reverb.get('dry_wet', .7)), int(reverb.get('n_echos', 10)),
                               int(cutoff_lfo), int(mod_target), len(effects),
                               (C.c_uint8 * 8)(*(effects + [0] * (MAX_FX - len(effects)))),
-                              int(gated), int(poly_voices))
+                              int(gated), int(poly_voices),
+                              int(reverb.get('rings', 'f64') == 'f32'), 0)
         self.effects = effects
         self.ctx = ctx
         self.n = int(n_voices)
@@ -340,9 +351,11 @@ class Bank:
             pass
 
     def set(self, field, values, first=0):
+        """Per-voice values for voices [first, first + len(values)); a true scalar (0-d) is
+        one value for every voice from `first` on.  A sequence of one value sets one voice."""
+        if np.ndim(values) == 0:
+            values = np.full(self.n - first, float(values))
         values = _f64(values).ravel()
-        if values.size == 1 and first == 0 and self.n > 1:
-            values = np.full(self.n, values[0])
         _check(load().klmi_bank_set_params(self._h, field, first, values.size, _p(values)))
 
     def get_state(self, field, first=0, count=None):

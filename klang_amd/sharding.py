@@ -34,11 +34,12 @@ def owner_of(voice, n_total, world_size):
     return extra + (voice - edge) // base
 
 
-def reduce_bus(bus, n_total, world_size, dst=0, group=None):
+def reduce_bus(bus, n_total, world_size, dst=0, group=None, always=False):
     """Sum the per-rank partial buses onto `dst` and apply mixer.py:46-47
     (divide by nInputs when nInputs > 1).  Works on CUDA tensors (RCCL) and CPU
-    tensors (gloo).  Returns the bus (meaningful on `dst` only)."""
-    if world_size > 1:
+    tensors (gloo).  Returns the bus (meaningful on `dst` only).  `always` issues the
+    collective in a world of one rank too (the same call path on a one-GPU box)."""
+    if world_size > 1 or always:
         dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if n_total > 1:
         bus /= float(n_total)
@@ -47,18 +48,21 @@ def reduce_bus(bus, n_total, world_size, dst=0, group=None):
 
 class ShardedMixer:
     """Renders this rank's bank and reduces the bus.  With world_size == 1 the
-    bank's own divisor is used and no collective is issued."""
+    bank's own divisor is used and no collective is issued, unless `always_reduce` asks for
+    the multi-rank path (un-normalised bus, reduce, division on the root) in a world of one."""
 
-    def __init__(self, bank, n_total, n_blocks, world_size=1, rank=0, group=None):
+    def __init__(self, bank, n_total, n_blocks, world_size=1, rank=0, group=None,
+                 always_reduce=False):
         self.bank = bank
         self.n_total = int(n_total)
         self.n_blocks = int(n_blocks)
         self.world_size = int(world_size)
         self.rank = rank
         self.group = group
+        self.collective = self.world_size > 1 or bool(always_reduce)
         self.bus = torch.zeros((self.n_blocks, bank.channels, BUFFER_SIZE), dtype=torch.float32,
                                device='cuda')
-        if self.world_size > 1:
+        if self.collective:
             bank.set_mix_divisor(1.)
         else:
             bank.set_mix_divisor(float(self.n_total) if self.n_total > 1 else 1.)
@@ -66,6 +70,6 @@ class ShardedMixer:
     def render(self):
         # launches are ordered on the torch stream the context was created with
         self.bank.render_device(self.n_blocks, self.bus.data_ptr())
-        if self.world_size > 1:
-            reduce_bus(self.bus, self.n_total, self.world_size, 0, self.group)
+        if self.collective:
+            reduce_bus(self.bus, self.n_total, self.world_size, 0, self.group, always=True)
         return self.bus

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(native.ChainDesc) == 88
+    assert ctypes.sizeof(native.ChainDesc) == 96
     assert native.EVENT_DTYPE.itemsize == 32 and native.NOTE_DTYPE.itemsize == 32
 
 

@@ -117,6 +117,35 @@ def test_reverb_chain_and_parameter_edits(hip, oracle):
     banks[0].close()
 
 
+def test_reverb_chains_under_a_stereo_mixer(hip):
+    """(Oscillator | Reverb) x N -> StereoMixer is ONE stereo bank with a Reverb per voice
+    (gain * pan per channel after the Reverb, mixer.py:95-104) and equals the host blocks."""
+    def build():
+        mixer = StereoMixer()
+        for k in range(5):
+            voice = Voice(Oscillator(wave_func=(sine, sawtooth)[k % 2]), AR(.01, .1))
+            rv = Reverb(decay=2., dryWet=.6)
+            voice | rv
+            mixer += rv
+            mixer.gains[-1] = .5 + .2 * k
+            mixer.pannings[-1] = -1. + .5 * k
+            voice.input.push(Note(60 + 3 * k, .9))
+        return mixer | Dac(nChannels=2)
+    order, banks = fusion.compile_order(determine_execution_order([build()]))
+    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac']
+    assert banks[0].bank.desc.stereo and banks[0].bank.desc.has_reverb
+    for bank in banks:
+        bank.close()
+    dur = 30 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0.))
+    want = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert got.shape == want.shape == (30 * B, 2) and np.abs(want).max() > .05
+    assert np.abs(want[:, 0] - want[:, 1]).max() > 1e-3
+    err = np.abs(got - want).max()
+    report('chain voice+reverb+stereo mixer', err)
+    assert err <= 1e-6
+
+
 def test_strict_backend_refuses_unfusable_hot_path_blocks(hip):
     from klang_amd.audio import Lfo
     lfo = Lfo(frequency=2., outputRange=(200., 2000.))       # control-rate Lfo ...

@@ -1,0 +1,146 @@
+"""BASELINE configs[3] at its stated size: 4,096 channels of Voice(sine, AR) -> Reverb ->
+Mixer with 0.46 GB of comb delay lines in HBM (effects.py:564-615, _filters.c:257-280),
+checked against the oracle -- mix, delay-line contents and ring positions -- plus the
+properties the kernel's launch structure must not break (time slabs of 1,024 samples, dry-bus
+chunks of 8 buffers), Reverb chains under a StereoMixer, and the measured cost of float32 ring
+storage."""
+import numpy as np
+import pytest
+
+from klang_amd import patches as P
+from tests.helpers import B, hip_bank_from_patch, library_table, oracle_bank_from_patch, report
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_reverb_channels(oracle, hip, patch, n_blocks, threads=8):
+    """The patch's dry voices through the oracle bank, then one oracle Reverb per channel:
+    -> (wet [n][n_blocks*256] float64, the Reverb objects)."""
+    table, grid = library_table(hip)
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    _, dry = ob.render(n_blocks, patch.events, want_voices=True,
+                       n_threads=min(threads, oracle.max_threads()))
+    kw = patch['reverb']
+    reverbs = [oracle.OracleReverb(kw['decay'], kw['pre_delay'], kw['dry_wet'], kw['n_echos'])
+               for _ in range(patch.n_voices)]
+    wet = np.stack([r.run(dry[v]) for v, r in enumerate(reverbs)])
+    return wet, reverbs
+
+
+def oracle_rings(reverb):
+    c = reverb.c
+    rings = [np.ctypeslib.as_array(c.filters[k].data, shape=(c.filters[k].length,)).copy()
+             for k in range(c.n_echos)]
+    return rings, [int(c.filters[k].position) for k in range(c.n_echos)]
+
+
+@pytest.mark.parametrize('wave,ring_tol', [('sine', 1e-12), ('sawtooth', 0.)])
+def test_config4_full_size_vs_oracle(hip, ctx, oracle, wave, ring_tol):
+    n, nb = 4096, 24
+    patch = P.reverb_patch(n_channels=n, n_blocks=nb, period=10, note_blocks=4)
+    if wave == 'sawtooth':   # plain float64 arithmetic end to end: delay lines bit for bit
+        patch['wave'] = np.full(n, P.WAVE_SAWTOOTH, dtype=np.int32)
+    rng = np.random.default_rng(7)
+    patch['gain'] = .5 + rng.random(n)
+    wet, reverbs = oracle_reverb_channels(oracle, hip, patch, nb)
+    want = (patch.gain[:, None] * wet).sum(axis=0).reshape(nb, B) / n
+    bank = hip_bank_from_patch(hip, ctx, patch)
+    mix = bank.render(nb)
+    assert mix.shape == (nb, 1, B) and np.abs(want).max() > 1e-2
+    err = np.abs(mix[:, 0, :] - want).max()
+    report('chain voice+reverb+mixer (4,096 channels)', err)
+    assert err <= 1e-6
+    taps, _ = hip.reverb_design(3., .03, 10)
+    for v in (0, 63, 64, 2047, 4095):
+        rings, pos = bank.reverb_state(v)
+        o_rings, o_pos = oracle_rings(reverbs[v])
+        assert list(pos) == o_pos == [(nb * B) % t for t in taps]
+        for got, ref in zip(rings, o_rings):
+            if ring_tol == 0.:
+                np.testing.assert_array_equal(got, ref)
+            else:
+                assert np.abs(got - ref).max() <= ring_tol
+    # the same span in calls that cut a 1,024-sample slab (3 | 6) and the 8-buffer dry-bus
+    # chunk (9 | 17) at other places: per-sample arithmetic and fold order do not change
+    again = hip_bank_from_patch(hip, ctx, patch)
+    parts = np.concatenate([again.render(k) for k in (3, 6, 8, 7)])
+    np.testing.assert_array_equal(parts, mix)
+    for v in (5, 4000):
+        for a, b in zip(again.reverb_state(v)[0], bank.reverb_state(v)[0]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_reverb_chains_into_a_stereo_mixer_vs_oracle(hip, ctx, oracle):
+    """(voice | Reverb) x N under a StereoMixer (mixer.py:95-104): each channel's Reverb
+    output goes to both buses with gain * pan; N is not a multiple of the wavefront."""
+    n, nb = 150, 20
+    patch = P.reverb_patch(n_channels=n, n_blocks=nb, period=9, note_blocks=3)
+    patch['stereo'] = True
+    rng = np.random.default_rng(3)
+    patch['pan'] = 2. * rng.random(n) - 1.
+    patch['gain'] = .25 + rng.random(n)
+    wet, _ = oracle_reverb_channels(oracle, hip, patch, nb)
+    pan = np.array([oracle.panning_amplitudes(p) for p in patch.pan])     # [n][2]
+    want = np.einsum('vc,vs->cs', patch.gain[:, None] * pan, wet) / n      # [2][span]
+    want = want.reshape(2, nb, B).transpose(1, 0, 2)
+    bank = hip_bank_from_patch(hip, ctx, patch)
+    mix = np.concatenate([bank.render(11), bank.render(9)])
+    assert mix.shape == (nb, 2, B) and np.abs(want).max() > 1e-2
+    err = np.abs(mix - want).max()
+    report('chain voice+reverb+stereo mixer', err)
+    assert err <= 1e-6
+    assert np.abs(mix[:, 0] - mix[:, 1]).max() > 1e-3      # two different buses
+
+
+def test_float32_ring_storage_measured(hip, ctx, oracle, golden):
+    """Reverb with float32 delay-line STORAGE (float64 arithmetic, one rounding per ring
+    write: 88 instead of 168 bytes per channel-sample).  Measures what that costs against
+    the float64 reference and holds it to the 1e-5 bound with margin: on the reference's own
+    impulse / noise fixtures and on a 512-buffer config-4 run, per channel (a one-hot gain
+    picks one channel's Reverb output out of a 64-channel bank) and on the comb outputs
+    themselves (the delay lines)."""
+    g = golden('reverb')
+    noise = golden('inputs')['noise']
+    impulse = np.zeros(24 * B)
+    impulse[0] = 1.
+    worst = 0.
+    for pname, kw in (('default', {}), ('decay3', dict(decay=3., dry_wet=.7))):
+        for iname, x in (('impulse', impulse), ('noise', noise)):
+            want = g['%s_%s' % (pname, iname)]
+            bank = hip.Bank(ctx, 1, has_env=False, has_reverb=True, reverb=dict(kw, rings='f32'))
+            bank.set(hip.F_WAVE, [hip.WAVE_EXTERNAL])
+            bank.set_input(x[None, :want.size])
+            got = bank.render(want.size // B)[:, 0, :].ravel()
+            worst = max(worst, np.abs(got - want).max())
+    report('reverb (float32 ring storage, fixtures)', worst)
+    assert worst <= 2e-6
+    # config 4, 512 buffers (the envelopes are re-gated every 86), 64 channels
+    n, nb = 64, 512
+    patch = P.reverb_patch(n_channels=n, n_blocks=nb)
+    wet, reverbs = oracle_reverb_channels(oracle, hip, patch, nb)
+    patch['reverb'] = dict(patch['reverb'], rings='f32')
+    out_err = ring_err = 0.
+    for v in (0, 17, 42, 63):
+        onehot = np.zeros(n)
+        onehot[v] = 1.
+        patch['gain'] = onehot
+        bank = hip_bank_from_patch(hip, ctx, patch)
+        bank.set_mix_divisor(1.)
+        got = bank.render(nb)[:, 0, :].ravel()
+        out_err = max(out_err, np.abs(got - wet[v]).max())
+        rings, pos = bank.reverb_state(v)
+        o_rings, o_pos = oracle_rings(reverbs[v])
+        assert list(pos) == o_pos
+        ring_err = max(ring_err, max(np.abs(a - b).max() for a, b in zip(rings, o_rings)))
+        bank.close()
+    report('reverb (float32 ring storage, config 4 x 512 buffers, per channel)', out_err)
+    report('reverb (float32 ring storage, comb outputs in the delay lines)', ring_err)
+    assert np.abs(wet).max() > .3
+    assert out_err <= 2e-6 and ring_err <= 5e-6

@@ -157,22 +157,25 @@ def config_synth(ctx):
                 launches=launches)
 
 
-def config4(ctx, n_channels=4096, n_blocks=512):
+def config4(ctx, n_channels=4096, n_blocks=512, rings='f64'):
     patch = patches.reverb_patch(n_channels=n_channels, n_blocks=n_blocks)
+    patch['reverb'] = dict(patch['reverb'], rings=rings)
     bank, ev = bank_for(ctx, patch)
     queue(bank, ev, n_blocks, 5)
     best, med = timed(lambda: bank.render(n_blocks))
     ms, launches = bank.last_kernel_ms()
     units = n_channels * n_blocks * B
-    algo = units * 168.   # 10 combs x (8 B read + 8 B write) float64 rings + 8 B dry input
+    width = 4 if rings == 'f32' else 8
+    per_sample = 10 * 2 * width + 8.   # 10 combs x (read + write) of a ring slot + 8 B dry input
+    algo = units * per_sample
     return dict(config='4: %d channels Voice(sine, AR(.01,1.)) -> Reverb(decay 3, dryWet .7) -> '
-                       'Mixer, %d blocks, float64 rings (%.2f GB of delay lines)'
-                       % (n_channels, n_blocks, n_channels * 13896 * 8 / 1e9),
+                       'Mixer, %d blocks, %s rings (%.2f GB of delay lines)'
+                       % (n_channels, n_blocks, rings, n_channels * 13896 * width / 1e9),
                 value=units / med, unit='channel-samples/s', wall_ms=med * 1e3,
                 reverb_kernel_ms=ms, reverb_launches=launches,
                 roofline=dict(bound='hbm', achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK,
                               unit='GB/s', frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK,
-                              kernel='reverb_kernel', algorithmic_bytes_per_channel_sample=168.,
+                              kernel='reverb_kernel', algorithmic_bytes_per_channel_sample=per_sample,
                               whole_call_frac=algo / med / 1e9 / HBM_PEAK))
 
 
@@ -202,6 +205,13 @@ def main():
             r = config_synth(ctx)
         elif w == '4big':
             r = config4(ctx, 16384, 128)
+        elif w == '4f32':
+            r = config4(ctx, rings='f32')
+        elif w == '4bigf32':
+            r = config4(ctx, 16384, 128, rings='f32')
+        elif w == 'probe':
+            r = dict(config='stream probe (klmi_ctx_stream_rate, 1 GiB buffers)',
+                     **{k: ctx.stream_rate(k) for k in ('copy', 'update', 'fill', 'sum')})
         else:
             raise SystemExit('unknown config %r' % w)
         print(json.dumps(r), flush=True)

@@ -5,7 +5,7 @@
 # Results land in gpurun_out/prof_*; tools/summarize_profiles.py turns them into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out && cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extra"
 run() {  # name, rocprofv3 options...
   local name=$1; shift
   rm -rf $R/gpurun_out/prof_$name

@@ -60,6 +60,7 @@ units = cfg['voices_per_gpu'] * cfg['blocks_per_step'] * 256 / bench['roofline']
 fetch_kb, write_kb = fetch['FETCH_SIZE'][0], write['WRITE_SIZE'][0]
 summary = {
     'kernel': name,
+    'round': tag,
     'voice_samples_per_launch': units,
     'FETCH_SIZE_KB_avg': fetch_kb,
     'WRITE_SIZE_KB_avg': write_kb,
