@@ -58,8 +58,8 @@ def extra_records(ctx, native, patches, torch, log):
     """The two HBM-bound shapes of the path, measured in this run (N == 1 only)."""
     out = {}
     rates = {k: ctx.stream_rate(k, 1 << 30, 10) for k in ('copy', 'update', 'fill')}
-    out['stream_probe_GBs'] = dict(rates, note='plain float4 grid-stride kernels of this library on '
-                                   '1 GiB buffers, bytes read + written (klmi_ctx_stream_rate)')
+    out['stream_probe_GBs'] = dict(rates, note='plain hand-written kernels of this library, one float4 per '
+                                   'lane, 1 GiB buffers, bytes read + written (klmi_ctx_stream_rate)')
     log('stream probe GB/s: %s' % ', '.join('%s %.0f' % kv for kv in rates.items()))
 
     def timed(bank, n_blocks, fn, runs=5):
@@ -114,6 +114,7 @@ def extra_records(ctx, native, patches, torch, log):
     for rings, per_sample in (('f32', 88.), ('f64', 168.)):
         patch['reverb'] = dict(patch['reverb'], rings=rings)
         bank = native.Bank(ctx, n, has_env=True, has_reverb=True, reverb=patch['reverb'])
+        assert bank.desc.reverb_rings_f64 == (rings == 'f64')
         bank.load_patch(no_events(patch))
         queue(bank, patch.events, nb, 6)
         bus = torch.empty((nb, 1, B), dtype=torch.float32, device='cuda')

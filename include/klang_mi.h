@@ -195,10 +195,12 @@ typedef struct {
                                  are addressed to instruments with klmi_bank_notes and routed
                                  on the device (synthesizer.py:200-209).  Implies gated; the
                                  default mix divisor is P (synthesizer.py:219) */
-    int32_t reverb_rings_f32; /* storage of the Reverb's delay lines: 0 float64 as in
-                                 _filters.c:33 (168 B of HBM traffic per channel-sample with
-                                 10 combs), 1 float32 (88 B; the comb arithmetic stays float64,
-                                 each ring write is rounded once) */
+    int32_t reverb_rings_f64; /* storage of the Reverb's delay lines: 0 float32 (88 B of HBM
+                                 traffic per channel-sample with 10 combs; the comb arithmetic
+                                 is float64 either way, each ring write is rounded once:
+                                 measured 1.4e-7 on a channel's output), 1 float64
+                                 as in _filters.c:33 (168 B; delay lines bit-identical to the
+                                 reference's) */
     int32_t reserved;
 } klmi_chain_desc;
 
@@ -250,8 +252,8 @@ int klmi_ctx_destroy(klmi_ctx *ctx);
 int klmi_ctx_synchronize(klmi_ctx *ctx);
 
 /* Measurement aid (no reference counterpart): the rate this GPU's memory system gives a
- * plain hand-written streaming kernel -- 16 bytes per lane and access, grid-stride -- over
- * `bytes` per buffer, `reps` timed launches (HIP events on the context's stream).  kind 0
+ * plain hand-written streaming kernel -- one 16-byte access per lane, one workgroup per
+ * 4 KiB in address order -- over `bytes` per buffer (at most 64 GiB), `reps` timed launches (HIP events on the context's stream).  kind 0
  * copy (read + write), 1 in-place update (read-modify-write, the Reverb kernel's access
  * mix), 2 fill (write only), 3 sum (read only).  gb_per_s counts bytes read + written.
  * bench.py quotes the HBM-bound kernels against it ("achievable") next to the 8 TB/s spec. */

@@ -51,55 +51,33 @@ __global__ void bus_finish_kernel(const double *__restrict__ stage, int slices, 
 }
 
 // Streaming probes for klmi_ctx_stream_rate: what this GPU's memory system gives a plain
-// hand-written kernel, as the yardstick for the HBM-bound kernels (16 bytes per lane and
-// access, grid-stride, 4 independent accesses in flight per lane).
+// hand-written kernel, as the yardstick for the HBM-bound kernels.  One 16-byte access per
+// lane, one workgroup per 4 KiB, workgroups dispatched in address order: the shape that
+// measured fastest on MI355X (tools/ubench/stream_probe.hip: grid-stride loops and several
+// accesses per lane in distant windows run 15-30 % slower).
 //   kind 0 copy   dst[i] = src[i]            (read + write, two buffers)
 //   kind 1 update buf[i] = buf[i] * a        (read-modify-write in place: the reverb's mix)
 //   kind 2 fill   dst[i] = a                 (write only)
-//   kind 3 sum    acc += src[i]              (read only; one store per thread at the end)
+//   kind 3 sum    keeps src[i] live          (read only)
 template <int KIND>
 __global__ __launch_bounds__(256) void stream_probe_kernel(const float4 *__restrict__ src,
                                                            float4 *__restrict__ dst, size_t n4,
                                                            float a)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        float4 v[4];
-        if constexpr (KIND != 2) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                v[k] = (KIND == 1 ? dst : src)[i + k * stride];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if constexpr (KIND == 0)
-                dst[i + k * stride] = v[k];
-            else if constexpr (KIND == 1)
-                dst[i + k * stride] = make_float4(v[k].x * a, v[k].y * a, v[k].z * a, v[k].w * a);
-            else if constexpr (KIND == 2)
-                dst[i + k * stride] = make_float4(a, a, a, a);
-            else
-                acc.x += v[k].x, acc.y += v[k].y, acc.z += v[k].z, acc.w += v[k].w;
-        }
-    }
-    for (; i < n4; i += stride) {
-        if constexpr (KIND == 0)
-            dst[i] = src[i];
-        else if constexpr (KIND == 1) {
-            const float4 v = dst[i];
-            dst[i] = make_float4(v.x * a, v.y * a, v.z * a, v.w * a);
-        } else if constexpr (KIND == 2)
-            dst[i] = make_float4(a, a, a, a);
-        else {
-            const float4 v = src[i];
-            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
-        }
-    }
-    if constexpr (KIND == 3) {
-        if (acc.x + acc.y + acc.z + acc.w == 12345.678f)   // keeps the loads alive
-            dst[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4)
+        return;
+    if constexpr (KIND == 0) {
+        dst[i] = src[i];
+    } else if constexpr (KIND == 1) {
+        const float4 v = dst[i];
+        dst[i] = make_float4(v.x * a, v.y * a, v.z * a, v.w * a);
+    } else if constexpr (KIND == 2) {
+        dst[i] = make_float4(a, a, a, a);
+    } else {
+        const float4 v = src[i];
+        if (v.x + v.y + v.z + v.w == 12345.678f)   // keeps the load alive, never true on zeros
+            dst[i] = v;
     }
 }
 

@@ -318,7 +318,7 @@ extern "C" int klmi_ctx_stream_rate(klmi_ctx *ctx, int kind, size_t bytes, int r
                                     double *gb_per_s)
 {
     TRY(use(ctx));
-    if (kind < 0 || kind > 3 || bytes < 4096 || reps < 1 || !gb_per_s)
+    if (kind < 0 || kind > 3 || bytes < 4096 || bytes > ((size_t)64 << 30) || reps < 1 || !gb_per_s)
         return fail(KLMI_E_ARG, "klmi_ctx_stream_rate: kind 0..3, bytes >= 4096, reps >= 1");
     const size_t n4 = bytes / sizeof(float4);
     DevBuf<float4> a, b;
@@ -334,7 +334,7 @@ extern "C" int klmi_ctx_stream_rate(klmi_ctx *ctx, int kind, size_t bytes, int r
     hipEvent_t t0, t1;
     HIP_TRY(hipEventCreate(&t0));
     HIP_TRY(hipEventCreate(&t1));
-    const dim3 grid((unsigned)std::min<size_t>((n4 + 255) / 256, (size_t)ctx->n_cus * 32)), block(256);
+    const dim3 grid((unsigned)((n4 + 255) / 256)), block(256);
     auto launch = [&] {
         const float4 *src = kind == 0 ? b.p : a.p;
         switch (kind) {
@@ -521,7 +521,7 @@ struct klmi_bank {
     ReverbState reverb;
     std::vector<int32_t> taps;
     std::vector<double> alphas;
-    DevBuf<double> rings, d_alphas;      // float64 delay lines (desc.reverb_rings_f32 == 0)
+    DevBuf<double> rings, d_alphas;      // float64 delay lines (desc.reverb_rings_f64 != 0)
     DevBuf<float> rings32;               // float32 storage of the same lines
     DevBuf<int32_t> d_taps, d_ring_offset;
     std::vector<int32_t> ring_pos;  // host-tracked, identical for every voice
@@ -1868,20 +1868,23 @@ static int bank_init_reverb(klmi_bank *b)
     for (int k = 0; k < r.n_echos; ++k) {
         r.length[k] = b->taps[k];
         r.alpha[k] = b->alphas[k];
-        r.offset[k] = (long long)total;
-        total += (size_t)b->taps[k];
+        r.offset[k] = (int)total + kReverbMirror;            // spare slots, then the ring,
+        total += (size_t)b->taps[k] + 2 * kReverbMirror;     // then its mirror slots
         min_tap = std::min(min_tap, b->taps[k]);
     }
     r.min_length = min_tap;
+    r.stride = (long long)total;   // voice-major: one run of all its combs per voice
     b->ring_pos.assign(r.n_echos, 0);
-    const bool f32 = d.reverb_rings_f32 != 0;
-    hipError_t e = f32 ? b->rings32.alloc(total * (size_t)b->n) : b->rings.alloc(total * (size_t)b->n);
+    const bool f32 = d.reverb_rings_f64 == 0;
+    // + spare slots behind the last voice's last mirror (second stores may reach them)
+    const size_t slots = total * (size_t)b->n + 2 * kReverbMirror;
+    hipError_t e = f32 ? b->rings32.alloc(slots) : b->rings.alloc(slots);
     if (e != hipSuccess)
         return fail(KLMI_E_MEMORY, "Reverb: could not allocate %zu ring samples: %s",
                     total * (size_t)b->n, hipGetErrorString(e));
     r.rings = f32 ? (void *)b->rings32.p : (void *)b->rings.p;
     // _filters.c:57 zero-initialised; ordered on the context's stream like the kernels
-    HIP_TRY(hipMemsetAsync(r.rings, 0, (f32 ? sizeof(float) : sizeof(double)) * total * (size_t)b->n,
+    HIP_TRY(hipMemsetAsync(r.rings, 0, (f32 ? sizeof(float) : sizeof(double)) * slots,
                            b->ctx->stream));
     return 0;
 }
@@ -1899,109 +1902,128 @@ static int reverb_streams(klmi_bank *b)
     return 0;
 }
 
-// Dry voices and reverb are pipelined over chunks of a few blocks: the voice
-// kernel of chunk j+1 (few waves, float64-VALU bound) runs on a side stream while
-// the reverb kernels of chunk j (HBM bound) run on the context's stream; two dry
-// buses alternate.  Order is carried by events only: ready[i] (dry bus i written),
-// done[i] (reverb finished reading dry bus i).
-template <int SPW>
-static void launch_reverb(bool f32, bool stereo, dim3 grid, hipStream_t st, const ReverbState &r,
-                          const double *x, int ns, const double *gl, const double *gr,
-                          float *partial, size_t stride)
+template <typename RingT, bool STEREO>
+static void launch_reverb_echos(int groups, hipStream_t st, const ReverbState &r, const double *x,
+                                size_t x_stride, int total, int pass, int vpw, const double *gl,
+                                const double *gr, float *partial, size_t row_stride)
+{
+    // The fast kernel is built for the Reverb's default of 10 combs (effects.py:575; its
+    // registers are sized for them) and passes of 256 samples; a comb shorter than that or
+    // another comb count takes the sample-per-lane kernel.
+    if (pass == kReverbPass && r.n_echos == 10)
+        hipLaunchKernelGGL((reverb_kernel<RingT, STEREO, 10>), dim3(groups), dim3(kReverbThreads), 0,
+                           st, r, x, x_stride, total, vpw, gl, gr, partial, row_stride);
+    else
+        hipLaunchKernelGGL((reverb_short_kernel<RingT, STEREO>), dim3(groups), dim3(kReverbThreads),
+                           0, st, r, x, x_stride, total, std::min(pass, 64), vpw, gl, gr, partial,
+                           row_stride);
+}
+
+static void launch_reverb(bool f32, bool stereo, int groups, hipStream_t st, const ReverbState &r,
+                          const double *x, size_t x_stride, int total, int pass, int vpw,
+                          const double *gl, const double *gr, float *partial, size_t row_stride)
 {
     if (f32) {
         if (stereo)
-            hipLaunchKernelGGL((reverb_kernel<SPW, float, true>), grid, dim3(64), 0, st, r, x, ns, gl,
-                               gr, partial, stride);
+            launch_reverb_echos<float, true>(groups, st, r, x, x_stride, total, pass, vpw, gl, gr, partial, row_stride);
         else
-            hipLaunchKernelGGL((reverb_kernel<SPW, float, false>), grid, dim3(64), 0, st, r, x, ns, gl,
-                               gr, partial, stride);
+            launch_reverb_echos<float, false>(groups, st, r, x, x_stride, total, pass, vpw, gl, gr, partial, row_stride);
     } else {
         if (stereo)
-            hipLaunchKernelGGL((reverb_kernel<SPW, double, true>), grid, dim3(64), 0, st, r, x, ns, gl,
-                               gr, partial, stride);
+            launch_reverb_echos<double, true>(groups, st, r, x, x_stride, total, pass, vpw, gl, gr, partial, row_stride);
         else
-            hipLaunchKernelGGL((reverb_kernel<SPW, double, false>), grid, dim3(64), 0, st, r, x, ns, gl,
-                               gr, partial, stride);
+            launch_reverb_echos<double, false>(groups, st, r, x, x_stride, total, pass, vpw, gl, gr, partial, row_stride);
     }
 }
 
+// Dry voices and reverb are pipelined over chunks of a few blocks: the voice kernel of
+// chunk j+1 (few waves, float64-VALU bound) runs on a side stream while the reverb kernel
+// of chunk j (HBM bound) runs on the context's stream; two dry buses alternate.  Order is
+// carried by events only: ready[i] (dry bus i written), done[i] (reverb finished reading
+// dry bus i).  One reverb launch covers the whole chunk: its waves own their voices and
+// walk the chunk's time passes themselves (reverb_kernels.h).
 static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
 {
     TRY(reverb_streams(b));
     hipStream_t st = b->ctx->stream, aux = b->aux_stream;
     ReverbState &r = b->reverb;
     const size_t n = (size_t)b->n;
-    const bool stereo = b->desc.stereo != 0, f32 = b->desc.reverb_rings_f32 != 0;
+    const bool stereo = b->desc.stereo != 0, f32 = b->desc.reverb_rings_f64 == 0;
     const int planes = stereo ? 2 : 1;
-    // time slab: as many samples as are independent of each other (< shortest ring),
-    // whole blocks when possible
-    int slab = std::min(r.min_length, 1024);
-    if (slab >= kBlock)
-        slab = (slab / kBlock) * kBlock;
-    const int slab_blocks = std::max(1, slab / kBlock);
-    const int chunk_blocks = std::min(n_blocks, std::max(slab_blocks, 8));
-    const size_t bus_elems = (size_t)chunk_blocks * kBlock * n;
+    // time pass: as many samples as are independent of each other (<= shortest ring)
+    const int pass = r.min_length >= kReverbPass ? kReverbPass : std::min(r.min_length, 64);
+    static const int chunk_pref = [] {
+        const char *e = getenv("KLMI_REVERB_CHUNK");   // tuning knob: blocks per chunk
+        const int v = e ? atoi(e) : 8;
+        return v >= 1 && v <= 64 ? v : 8;
+    }();
+    const int chunk_blocks = std::min(n_blocks, chunk_pref);
+    const size_t chunk_samples = (size_t)chunk_blocks * kBlock;
+    // dry bus [voice][bus_stride]: rows are 256 bytes longer than the chunk, so that the
+    // rows of consecutive voices -- read at the same sample offset by all waves at about
+    // the same time -- do not start a power-of-two apart
+    const size_t bus_stride = chunk_samples + 32;
+    const size_t bus_elems = bus_stride * n;
     HIP_TRY(b->bus_f64.reserve(2 * bus_elems));
-    const int wave_groups = (b->n + 63) / 64;
-    const size_t partial_stride = (size_t)chunk_blocks * kBlock;
-    const size_t partial_elems = (size_t)wave_groups * planes * partial_stride;
+    // voices per wave: enough waves for 16 per compute unit, at most 16 voices each
+    static const int vpw_forced = [] {
+        const char *e = getenv("KLMI_REVERB_VPW");     // tuning knob
+        return e ? atoi(e) : 0;
+    }();
+    int vpw = (b->n + 16 * b->ctx->n_cus - 1) / (16 * b->ctx->n_cus);
+    vpw = std::max(1, std::min(vpw, kReverbVoicesPerWaveMax));
+    if (vpw_forced >= 1 && vpw_forced <= 64)
+        vpw = vpw_forced;
+    const int waves = (b->n + vpw - 1) / vpw;
+    const int groups = (waves + kReverbWaves - 1) / kReverbWaves;
+    const int rows = groups * kReverbWaves;          // partial rows, one per wave
+    const int slices = bus_slices(rows);
+    const size_t row_stride = chunk_samples * planes;
+    const size_t partial_elems = (size_t)rows * row_stride;
     HIP_TRY(b->rv_partial.reserve(2 * partial_elems));
+    HIP_TRY(b->stage.reserve((size_t)slices * row_stride));
     BankView view = make_view(b);
     b->timed_launches = 0;
     // the side stream starts after everything already queued on the main stream
     HIP_TRY(hipEventRecord(b->rv_start, st));
     HIP_TRY(hipStreamWaitEvent(aux, b->rv_start, 0));
-    static const int spw = [] {
-        const char *e = getenv("KLMI_REVERB_SPW");   // tuning knob, default 4
-        const int v = e ? atoi(e) : kReverbSamplesPerWave;
-        return (v == 2 || v == 8) ? v : 4;
-    }();
     int chunk = 0;
     for (int base = 0; base < n_blocks; base += chunk_blocks, ++chunk) {
         const int nb = std::min(chunk_blocks, n_blocks - base);
         const int buf = chunk & 1;
         double *bus = b->bus_f64.p + (size_t)buf * bus_elems;
         float *partial = b->rv_partial.p + (size_t)buf * partial_elems;
-        // 1) dry voices for nb blocks -> bus[sample][voice], on the side stream
+        // 1) dry voices for nb blocks -> bus[voice][sample], on the side stream
         if (chunk >= 2)
             HIP_TRY(hipStreamWaitEvent(aux, b->rv_done[buf], 0));
-        hipError_t e = dispatch_voice<OUT_BUS_F64>(b->desc.has_env, b->desc.has_filter, aux, view,
-                                                   0, b->n, base, b->block_clock + (uint32_t)base,
-                                                   nb, 0, nullptr, bus);
+        hipError_t e = dispatch_voice<OUT_VOICES_F64>(b->desc.has_env, b->desc.has_filter, aux, view,
+                                                      0, b->n, base, b->block_clock + (uint32_t)base,
+                                                      nb, (int)bus_stride, nullptr, bus);
         if (e != hipSuccess)
             return fail(KLMI_E_DEVICE, "voice kernel launch failed: %s", hipGetErrorString(e));
         HIP_TRY(hipEventRecord(b->rv_ready[buf], aux));
         HIP_TRY(hipStreamWaitEvent(st, b->rv_ready[buf], 0));
-        // 2) combs + dry/wet + cross-voice sum, one launch per independent time slab
+        // 2) combs + dry/wet + per-wave voice sums for the whole chunk
         const int total = nb * kBlock;
-        for (int s0 = 0; s0 < total; s0 += slab) {
-            const int ns = std::min(slab, total - s0);
-            for (int k = 0; k < r.n_echos; ++k)
-                r.position[k] = b->ring_pos[k];
-            TRY(timing_begin(b, b->timed_launches));
-            const dim3 grid((unsigned)wave_groups, (unsigned)((ns + spw - 1) / spw));
-            const double *x = bus + (size_t)s0 * n;
-            if (spw == 2)
-                launch_reverb<2>(f32, stereo, grid, st, r, x, ns, b->gain_l.p, b->gain_r.p,
-                                 partial + (size_t)s0, partial_stride);
-            else if (spw == 8)
-                launch_reverb<8>(f32, stereo, grid, st, r, x, ns, b->gain_l.p, b->gain_r.p,
-                                 partial + (size_t)s0, partial_stride);
-            else
-                launch_reverb<4>(f32, stereo, grid, st, r, x, ns, b->gain_l.p, b->gain_r.p,
-                                 partial + (size_t)s0, partial_stride);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
-            b->timed_launches++;
-            for (int k = 0; k < r.n_echos; ++k)
-                b->ring_pos[k] = (b->ring_pos[k] + ns) % r.length[k];
-        }
+        const size_t bus_len = (size_t)total * planes;   // [block][plane][256]
+        for (int k = 0; k < r.n_echos; ++k)
+            r.position[k] = b->ring_pos[k];
+        TRY(timing_begin(b, b->timed_launches));
+        launch_reverb(f32, stereo, groups, st, r, bus, bus_stride, total, pass, vpw, b->gain_l.p,
+                      b->gain_r.p, partial, bus_len);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
+        b->timed_launches++;
+        for (int k = 0; k < r.n_echos; ++k)
+            b->ring_pos[k] = (int)(((long long)b->ring_pos[k] + total) % r.length[k]);
         HIP_TRY(hipEventRecord(b->rv_done[buf], st));
-        const size_t bus_len = (size_t)total;
-        hipLaunchKernelGGL(bus_reduce_strided_kernel, dim3((unsigned)((bus_len + 255) / 256)),
-                           dim3(256), 0, st, partial, wave_groups, planes, partial_stride, bus_len,
-                           b->mix_divisor, dev_mix + (size_t)base * planes * kBlock);
+        // 3) fixed-order fold of the rows (the mixer's sum over voices), / divisor -> float32
+        hipLaunchKernelGGL(bus_slice_kernel, dim3((unsigned)((bus_len + 1023) / 1024), slices),
+                           dim3(256), 0, st, partial, rows, bus_len, b->stage.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bus_finish_kernel, dim3((unsigned)((bus_len + 255) / 256)), dim3(256), 0,
+                           st, b->stage.p, slices, bus_len, b->mix_divisor,
+                           dev_mix + (size_t)base * planes * kBlock);
         HIP_TRY(hipGetLastError());
     }
     b->block_clock += (uint32_t)n_blocks;
@@ -2021,19 +2043,24 @@ extern "C" int klmi_bank_reverb_state_get(klmi_bank *b, int voice, double *rings
         return fail(KLMI_E_ARG, "klmi_bank_reverb_state_get: voice %d out of range", voice);
     TRY(use(b->ctx));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    size_t total = 0;
-    for (int t : b->taps)
-        total += (size_t)t;
-    // rings are [slot][voice]: strided gather of one voice
-    if (b->desc.reverb_rings_f32) {
-        std::vector<float> tmp(total);
-        HIP_TRY(hipMemcpy2D(tmp.data(), sizeof(float), b->rings32.p + voice, sizeof(float) * b->n,
-                            sizeof(float), total, hipMemcpyDeviceToHost));
-        std::copy(tmp.begin(), tmp.end(), rings);
+    // rings are [voice][comb: ring + mirror slots]: one contiguous run per voice
+    const size_t run = (size_t)b->reverb.stride;
+    std::vector<double> tmp64;
+    std::vector<float> tmp32;
+    if (b->desc.reverb_rings_f64 == 0) {
+        tmp32.resize(run);
+        HIP_TRY(hipMemcpy(tmp32.data(), b->rings32.p + (size_t)voice * run, sizeof(float) * run,
+                          hipMemcpyDeviceToHost));
     } else {
-        HIP_TRY(hipMemcpy2D(rings, sizeof(double), b->rings.p + voice, sizeof(double) * b->n,
-                            sizeof(double), total, hipMemcpyDeviceToHost));
+        tmp64.resize(run);
+        HIP_TRY(hipMemcpy(tmp64.data(), b->rings.p + (size_t)voice * run, sizeof(double) * run,
+                          hipMemcpyDeviceToHost));
     }
+    size_t out = 0;
+    for (size_t k = 0; k < b->taps.size(); ++k)
+        for (int i = 0; i < b->taps[k]; ++i, ++out)
+            rings[out] = b->desc.reverb_rings_f64 == 0 ? (double)tmp32[(size_t)b->reverb.offset[k] + i]
+                                                  : tmp64[(size_t)b->reverb.offset[k] + i];
     for (size_t k = 0; k < b->taps.size(); ++k)
         positions[k] = b->ring_pos[k];
     return 0;

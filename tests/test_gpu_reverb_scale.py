@@ -1,9 +1,9 @@
 """BASELINE configs[3] at its stated size: 4,096 channels of Voice(sine, AR) -> Reverb ->
 Mixer with 0.46 GB of comb delay lines in HBM (effects.py:564-615, _filters.c:257-280),
 checked against the oracle -- mix, delay-line contents and ring positions -- plus the
-properties the kernel's launch structure must not break (time slabs of 1,024 samples, dry-bus
-chunks of 8 buffers), Reverb chains under a StereoMixer, and the measured cost of float32 ring
-storage."""
+properties the kernel's launch structure must not break (passes of 256 samples with ring ends
+inside them, dry-bus chunks of 8 buffers), Reverb chains under a StereoMixer, reverbs that take
+the sample-per-lane kernel, and the measured cost of float32 ring storage (the default)."""
 import numpy as np
 import pytest
 
@@ -27,7 +27,7 @@ def oracle_reverb_channels(oracle, hip, patch, n_blocks, threads=8):
     ob = oracle_bank_from_patch(oracle, patch, table, grid)
     _, dry = ob.render(n_blocks, patch.events, want_voices=True,
                        n_threads=min(threads, oracle.max_threads()))
-    kw = patch['reverb']
+    kw = patch['reverb']     # (its 'rings' entry is the device's storage choice: not the oracle's)
     reverbs = [oracle.OracleReverb(kw['decay'], kw['pre_delay'], kw['dry_wet'], kw['n_echos'])
                for _ in range(patch.n_voices)]
     wet = np.stack([r.run(dry[v]) for v, r in enumerate(reverbs)])
@@ -41,11 +41,16 @@ def oracle_rings(reverb):
     return rings, [int(c.filters[k].position) for k in range(c.n_echos)]
 
 
-@pytest.mark.parametrize('wave,ring_tol', [('sine', 1e-12), ('sawtooth', 0.)])
-def test_config4_full_size_vs_oracle(hip, ctx, oracle, wave, ring_tol):
+@pytest.mark.parametrize('wave,rings,ring_tol', [('sine', 'f32', 2e-6), ('sine', 'f64', 1e-12),
+                                                 ('sawtooth', 'f64', 0.)])
+def test_config4_full_size_vs_oracle(hip, ctx, oracle, wave, rings, ring_tol):
+    """float32 ring storage is the default; float64 storage reproduces the reference's delay
+    lines to the sine's ulps, and bit for bit under a sawtooth (plain float64 arithmetic end
+    to end)."""
     n, nb = 4096, 24
     patch = P.reverb_patch(n_channels=n, n_blocks=nb, period=10, note_blocks=4)
-    if wave == 'sawtooth':   # plain float64 arithmetic end to end: delay lines bit for bit
+    patch['reverb'] = dict(patch['reverb'], rings=rings)
+    if wave == 'sawtooth':
         patch['wave'] = np.full(n, P.WAVE_SAWTOOTH, dtype=np.int32)
     rng = np.random.default_rng(7)
     patch['gain'] = .5 + rng.random(n)
@@ -67,8 +72,8 @@ def test_config4_full_size_vs_oracle(hip, ctx, oracle, wave, ring_tol):
                 np.testing.assert_array_equal(got, ref)
             else:
                 assert np.abs(got - ref).max() <= ring_tol
-    # the same span in calls that cut a 1,024-sample slab (3 | 6) and the 8-buffer dry-bus
-    # chunk (9 | 17) at other places: per-sample arithmetic and fold order do not change
+    # the same span in calls that cut the 8-buffer dry-bus chunks at other places: per-sample
+    # arithmetic and fold order do not change
     again = hip_bank_from_patch(hip, ctx, patch)
     parts = np.concatenate([again.render(k) for k in (3, 6, 8, 7)])
     np.testing.assert_array_equal(parts, mix)
@@ -97,6 +102,31 @@ def test_reverb_chains_into_a_stereo_mixer_vs_oracle(hip, ctx, oracle):
     report('chain voice+reverb+stereo mixer', err)
     assert err <= 1e-6
     assert np.abs(mix[:, 0] - mix[:, 1]).max() > 1e-3      # two different buses
+
+
+def test_other_comb_counts_and_short_combs_vs_oracle(hip, ctx, oracle):
+    """nEchos != 10 and combs shorter than 256 samples run in the sample-per-lane kernel."""
+    rng = np.random.default_rng(11)
+    for kw in (dict(decay=2., pre_delay=.03, dry_wet=.5, n_echos=7),
+               dict(decay=1., pre_delay=.002, dry_wet=.9, n_echos=10),
+               dict(decay=.7, pre_delay=.0001, dry_wet=.6, n_echos=16)):
+        n, nb = 70, 12
+        patch = P.reverb_patch(n_channels=n, n_blocks=nb, period=5, note_blocks=2)
+        patch['reverb'] = dict(kw, rings='f64')
+        patch['wave'] = np.full(n, P.WAVE_SAWTOOTH, dtype=np.int32)
+        patch['gain'] = .5 + rng.random(n)
+        wet, reverbs = oracle_reverb_channels(oracle, hip, patch, nb)
+        want = (patch.gain[:, None] * wet).sum(axis=0).reshape(nb, B) / n
+        bank = hip_bank_from_patch(hip, ctx, patch)
+        mix = np.concatenate([bank.render(5), bank.render(7)])[:, 0, :]
+        assert np.abs(want).max() > 1e-2 and np.abs(mix - want).max() <= 1e-6
+        for v in (0, 69):
+            rings, pos = bank.reverb_state(v)
+            o_rings, o_pos = oracle_rings(reverbs[v])
+            assert list(pos) == o_pos
+            for got, ref in zip(rings, o_rings):
+                np.testing.assert_array_equal(got, ref)
+        bank.close()
 
 
 def test_float32_ring_storage_measured(hip, ctx, oracle, golden):
