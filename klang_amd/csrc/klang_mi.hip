@@ -1462,6 +1462,23 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
     // synthesizer voices (oscillator x envelope under a mixer) have a gated form of the fast kernel
     const bool fast_gated = env && !filt && view.n_fx == 0 &&
                             (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
+    // banks that leave most SIMDs idle spread every voice over a group of lanes
+    int n_cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        static int cached[64] = {};
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (!cached[dev] && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cached[dev] = prop.multiProcessorCount;
+            if (cached[dev] > 0)
+                n_cus = cached[dev];
+        }
+    }
+    const int wide = wide_lanes_log2(view, count, MODE, n_cus);
+    if (wide > 0)
+        return launch_wide_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
+                                  n_blocks, span_total, wide, partial, out);
     if (view.mod_target != MT_NONE || !plain_chain || (view.gated && !fast_gated))
         return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                  n_blocks, span_total, partial, out);
@@ -1518,9 +1535,10 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix, unsigned char 
         return render_reverb(b, n_blocks, dev_mix);
     hipStream_t st = b->ctx->stream;
     const int planes = b->desc.stereo ? 2 : 1;
-    const int groups = (b->n + kGroup - 1) / kGroup;
-    // one partial bus per wave (64 voices); blocks per launch keep them within 256 MiB
-    const int rows = groups * kWavesPerGroup;
+    BankView view = make_view(b);
+    // one partial bus per wave; blocks per launch keep them within 256 MiB
+    const int rows = voice_partial_rows(view, b->n, b->desc.stereo ? OUT_MIX_STEREO : OUT_MIX_MONO,
+                                        b->ctx->n_cus);
     const int slices = bus_slices(rows);
     const size_t per_block = (size_t)rows * planes * kBlock * sizeof(float);
     const size_t stage_per_block = (size_t)slices * planes * kBlock * sizeof(double);
@@ -1545,7 +1563,6 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix, unsigned char 
         partial = reinterpret_cast<float *>(fixed);
         stage = reinterpret_cast<double *>(fixed + per_block * (size_t)bpl);
     }
-    BankView view = make_view(b);
     b->timed_launches = 0;
     for (int base = 0; base < n_blocks; base += bpl) {
         const int nb = std::min(bpl, n_blocks - base);

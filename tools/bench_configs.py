@@ -52,8 +52,8 @@ def queue(bank, ev, n_blocks, runs):
     bank.events(np.concatenate(allev))
 
 
-def config2(ctx):
-    n_blocks, replicas = 2048, 1024
+def config2(ctx, replicas=1024):
+    n_blocks = 2048
     patch = patches.haunting_patch(replicas=replicas, n_blocks=n_blocks)
     bank, ev = bank_for(ctx, patch)
     bank.events(ev)
@@ -189,6 +189,8 @@ def main():
     for w in which:
         if w == '2':
             r = config2(ctx)
+        elif w == '2native':
+            r = config2(ctx, 1)
         elif w == '3m':
             r = config3_materialised(ctx)
         elif w == '4':
