@@ -1462,7 +1462,7 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
     // synthesizer voices (oscillator x envelope under a mixer) have a gated form of the fast kernel
     const bool fast_gated = env && !filt && view.n_fx == 0 &&
                             (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
-    // banks that leave most SIMDs idle spread every voice over a group of lanes
+    // banks that leave most SIMDs idle run oscillator / chain / output as pipeline stages
     int n_cus = 256;
     {
         int dev = 0;
@@ -1475,10 +1475,10 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
                 n_cus = cached[dev];
         }
     }
-    const int wide = wide_lanes_log2(view, count, MODE, n_cus);
-    if (wide > 0)
-        return launch_wide_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
-                                  n_blocks, span_total, wide, partial, out);
+    const int pipe = pipe_voices_log2(view, filt, count, MODE, n_cus);
+    if (pipe >= 0)
+        return launch_pipe_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
+                                  n_blocks, span_total, pipe, partial, out);
     if (view.mod_target != MT_NONE || !plain_chain || (view.gated && !fast_gated))
         return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                  n_blocks, span_total, partial, out);
@@ -1537,7 +1537,8 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix, unsigned char 
     const int planes = b->desc.stereo ? 2 : 1;
     BankView view = make_view(b);
     // one partial bus per wave; blocks per launch keep them within 256 MiB
-    const int rows = voice_partial_rows(view, b->n, b->desc.stereo ? OUT_MIX_STEREO : OUT_MIX_MONO,
+    const int rows = voice_partial_rows(view, b->desc.has_filter != 0, b->n,
+                                        b->desc.stereo ? OUT_MIX_STEREO : OUT_MIX_MONO,
                                         b->ctx->n_cus);
     const int slices = bus_slices(rows);
     const size_t per_block = (size_t)rows * planes * kBlock * sizeof(float);

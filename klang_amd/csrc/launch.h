@@ -39,15 +39,15 @@ hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, cons
                              int first, int count, int block_base, uint32_t clock_base,
                              int n_blocks, int span_total, float *partial, void *out);
 
-// Banks that do not fill the chip (wide_kernels.h): log2 of the lanes a voice is spread over,
-// 0 when the chain, the mode or the size asks for the one-lane-per-voice kernels; the
-// launcher; and the number of partial-bus rows a mix launch of `count` voices writes
-// (one per wave, a multiple of 4) whichever kernel takes it.
-int wide_lanes_log2(const BankView &view, int count, int mode, int n_cus);
-int voice_partial_rows(const BankView &view, int count, int mode, int n_cus);
-hipError_t launch_wide_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
+// Banks that do not fill the chip (pipe_kernels.h): log2 of the voices a workgroup of the
+// pipelined kernel owns, -1 when the chain, the mode or the size asks for the
+// one-lane-per-voice kernels; the launcher; and the number of partial-bus rows a mix launch
+// of `count` voices writes whichever kernel takes it.
+int pipe_voices_log2(const BankView &view, bool filt, int count, int mode, int n_cus);
+int voice_partial_rows(const BankView &view, bool filt, int count, int mode, int n_cus);
+hipError_t launch_pipe_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                               int first, int count, int block_base, uint32_t clock_base,
-                              int n_blocks, int span_total, int lanes_log2, float *partial,
+                              int n_blocks, int span_total, int voices_log2, float *partial,
                               void *out);
 
 }  // namespace klmi
