@@ -1,5 +1,12 @@
-"""Mono and stereo mixers (klang/audio/mixer.py:15-104) and panning
-(klang/audio/panning.py:35-81), host side."""
+"""Mono and stereo mixers (the reference's klang/audio/mixer.py:15-104 and
+klang/audio/panning.py:35-81), host side.
+
+A mixer is a list of channels; each contributes ``weight * signal`` to the bus, and a bus
+with more than one channel is divided by the channel count (mixer.py:46-47).  The two
+mixers differ only in the weight: the channel's gain, or gain * (left, right) amplitudes of
+its pan position.  The pan law itself is computed by the library's host helper
+(klmi_panning_amplitudes), the same one the device banks are parameterised with.
+"""
 from klang_amd import native
 from klang_amd.audio.signals import MONO_SILENCE, STEREO_SILENCE
 from klang_amd.block import Block, fetch_output
@@ -12,8 +19,8 @@ LEFT, CENTER, RIGHT = -1., 0., 1.
 
 
 def panning_amplitudes(panLevel, mode='constant_power', panLaw=None):
-    """(2, 1) array of left/right amplitudes; ValueError for an unknown mode or
-    a positive pan law (panning.py:49-52).  Computed by klmi_panning_amplitudes."""
+    """(2, 1) array of left / right amplitudes; ValueError for an unknown mode or a positive
+    pan law (panning.py:49-52)."""
     return native.panning_amplitudes(panLevel, mode, panLaw).reshape(2, 1)
 
 
@@ -22,54 +29,61 @@ def pan_signal(signal, panLevel, mode='constant_power', panLaw=None):
     return panning_amplitudes(panLevel, mode, panLaw) * signal
 
 
+def _per_channel(values, count, default):
+    values = count * [default] if values is None else values
+    assert len(values) == count
+    return values
+
+
 class Mixer(Block):
-    """Gain-weighted mean of its inputs (a sum for a single input)."""
+    """Gain-weighted mean of its inputs (a plain weighted sum for a single input)."""
+
+    silence = MONO_SILENCE
 
     def __init__(self, nInputs=0, gains=None):
-        if gains is None:
-            gains = nInputs * [DEFAULT_GAIN]
-        assert len(gains) == nInputs
         super().__init__(nInputs=nInputs, nOutputs=1)
-        self.gains = gains
+        self.gains = _per_channel(gains, nInputs, DEFAULT_GAIN)
 
     def add_new_channel(self, gain=DEFAULT_GAIN):
-        self.inputs.append(Input(owner=self))
         self.gains.append(gain)
+        self.inputs.append(Input(owner=self))
+
+    def weight(self, channel):
+        """What channel number `channel` is multiplied with."""
+        return self.gains[channel]
 
     def update(self):
-        total = MONO_SILENCE.copy()
-        for gain, channel in zip(self.gains, self.inputs):
-            total += gain * channel.value
-        if self.nInputs > 1:
-            total = total / self.nInputs
-        self.output.set_value(total)
+        bus = self.silence.copy()
+        for number, port in enumerate(self.inputs):
+            bus += self.weight(number) * port.get_value()
+        self.output.set_value(bus / len(self.inputs) if len(self.inputs) > 1 else bus)
 
-    def __iadd__(self, other):
+    def attach(self, source):
+        """`source` (a block or an output) on a new channel; the mixer itself is returned, so
+        that ``mixer += a``, ``mixer + a`` and ``a + mixer`` all extend this mixer
+        (mixer.py:51-61)."""
         self.add_new_channel()
-        fetch_output(other).connect(self.inputs[-1])
+        fetch_output(source).connect(self.inputs[-1])
         return self
 
-    __add__ = __iadd__
-    __radd__ = __iadd__
+    __iadd__ = __add__ = __radd__ = attach
 
 
 class StereoMixer(Mixer):
+    """Every channel is placed in the stereo field by its pan level (mixer.py:64-104)."""
+
+    silence = STEREO_SILENCE
+
     def __init__(self, nInputs=0, gains=None, pannings=None, mode='constant_power',
                  panLaw=None):
-        if pannings is None:
-            pannings = nInputs * [CENTER]
-        assert len(pannings) == nInputs
         super().__init__(nInputs, gains=gains)
-        self.mode, self.panLaw, self.pannings = mode, panLaw, pannings
+        self.pannings = _per_channel(pannings, nInputs, CENTER)
+        self.mode, self.panLaw = mode, panLaw
 
     def add_new_channel(self, gain=DEFAULT_GAIN, panning=CENTER):
         super().add_new_channel(gain)
         self.pannings.append(panning)
 
-    def update(self):
-        total = STEREO_SILENCE.copy()
-        for gain, panning, channel in zip(self.gains, self.pannings, self.inputs):
-            total += gain * panning_amplitudes(panning, self.mode, self.panLaw) * channel.get_value()
-        if self.nInputs > 1:
-            total = total / self.nInputs
-        self.output.set_value(total)
+    def weight(self, channel):
+        return self.gains[channel] * panning_amplitudes(self.pannings[channel], self.mode,
+                                                        self.panLaw)

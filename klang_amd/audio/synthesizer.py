@@ -14,7 +14,6 @@ goes in as the voice's external input (fusion.GpuHiHat).
 """
 import copy
 import heapq
-import itertools
 import math
 
 import numpy as np
@@ -30,78 +29,87 @@ __all__ = ['NoteScheduler', 'Synthesizer', 'MonophonicSynthesizer', 'PolyphonicS
 
 
 def duplicate_voice(voice, number):
-    """`number` copies of a voice (synthesizer.py:58-60)."""
-    return [copy.deepcopy(voice, memo=None) for _ in range(number)]
+    """`number` independent copies of a voice (synthesizer.py:58-60)."""
+    return [copy.deepcopy(voice) for _ in range(number)]
 
 
 class Synthesizer(Block):
-    """Base class: one message input, one mono output (synthesizer.py:63-84)."""
+    """Base class: one message input, one mono output; every note that arrives in a buffer
+    goes through ``process_note`` (synthesizer.py:63-84)."""
 
     def __init__(self):
         super().__init__(nOutputs=1)
         self.inputs = [MessageInput(owner=self)]
         self.output.set_value(MONO_SILENCE)
 
-    def play_note(self, *notes):
-        for note in notes:
-            self.process_note(note)
-
     def process_note(self, note):
         raise NotImplementedError
 
-    def update(self):
-        for note in self.input.receive():
+    def play_note(self, *notes):
+        """Notes handed over directly instead of through the message input."""
+        for note in notes:
             self.process_note(note)
+
+    def update(self):
+        self.play_note(*self.input.receive())
+
+
+# priority of a held note under each policy of the monophonic synthesizer: the note with
+# the SMALLEST rank plays (`arrival` counts the note-ons seen so far)
+_RANKS = {
+    'newest': lambda note, arrival: -arrival,
+    'oldest': lambda note, arrival: arrival,
+    'highest': lambda note, arrival: -note.pitch,
+    'lowest': lambda note, arrival: note.pitch,
+}
 
 
 class NoteScheduler:
-    """The sounding note-ons of a monophonic synthesizer, ordered by policy
-    (synthesizer.py:87-148): a min-heap over the reversed key; a note-off removes
-    the first entry of that pitch."""
+    """Which of the held notes a monophonic synthesizer plays (synthesizer.py:87-148).
 
-    POLICIES = ('newest', 'oldest', 'lowest', 'highest')
+    Held note-ons live in a binary heap (``heapq``) of (rank, note) entries, the playing note
+    on top.  A note-off drops the first entry of its pitch in the heap's own array order --
+    which entry that is matters when a pitch is held twice, and the reference's behaviour is
+    defined by exactly this container -- and restores the heap."""
+
+    POLICIES = tuple(_RANKS)
 
     def __init__(self, policy='newest'):
-        assert policy in self.POLICIES
+        assert policy in _RANKS
         self.policy = policy
-        self.counter = itertools.count()
-        self.notes = []
+        self.arrivals = 0
+        self.notes = []     # the heap
 
-    def get_key(self, note):
-        if self.policy == 'newest':
-            key = next(self.counter)
-        elif self.policy == 'oldest':
-            key = -next(self.counter)
-        elif self.policy == 'highest':
-            key = note.pitch
-        else:
-            key = -note.pitch
-        return -key
+    def hold(self, note):
+        heapq.heappush(self.notes, (_RANKS[self.policy](note, self.arrivals), note))
+        self.arrivals += 1
 
-    def add_note(self, note):
-        heapq.heappush(self.notes, (self.get_key(note), note))
-
-    def remove_note(self, note):
-        for item in self.notes:
-            if item[1].pitch == note.pitch:
-                self.notes.remove(item)
-                heapq.heapify(self.notes)
-                return
+    def release(self, pitch):
+        position = next((i for i, (_, held) in enumerate(self.notes) if held.pitch == pitch), None)
+        if position is not None:
+            del self.notes[position]
+            heapq.heapify(self.notes)
 
     def get_next_note(self, note):
-        """The note the voice has to play now, given a new note-on / note-off."""
+        """The note the voice has to play now, given a new note-on / note-off: the top of
+        the heap, or the note itself when nothing is held any more."""
         if note.on:
-            self.add_note(note)
+            self.hold(note)
         else:
-            self.remove_note(note)
-        if not self.notes:
-            return note
-        return self.notes[0][1]
+            self.release(note.pitch)
+        return self.notes[0][1] if self.notes else note
+
+    # the reference's names
+    def add_note(self, note):
+        self.hold(note)
+
+    def remove_note(self, note):
+        self.release(note.pitch)
 
 
 class MonophonicSynthesizer(Synthesizer):
-    """One voice; the scheduler decides which held note it plays
-    (synthesizer.py:151-181).  The voice is only updated while active."""
+    """One voice; the scheduler decides which held note it plays (synthesizer.py:151-181).
+    The voice is only updated while active; otherwise the output is silence."""
 
     def __init__(self, voice, policy='newest'):
         super().__init__()
@@ -113,80 +121,114 @@ class MonophonicSynthesizer(Synthesizer):
 
     def update(self):
         super().update()
-        samples = MONO_SILENCE
-        if self.voice.active:
-            self.voice.update()
-            samples = self.voice.output.value
-        self.output.set_value(samples)
+        if not self.voice.active:
+            self.output.set_value(MONO_SILENCE)
+            return
+        self.voice.update()
+        self.output.set_value(self.voice.output.value)
+
+
+class RoundRobin:
+    """Endless iterator over the voices of a polyphonic synthesizer; ``taken`` counts how many
+    it has handed out (the device bank is told ``taken % len(voices)``)."""
+
+    def __init__(self, voices):
+        self.voices = voices
+        self.taken = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        voice = self.voices[self.taken % len(self.voices)]
+        self.taken += 1
+        return voice
 
 
 class PolyphonicSynthesizer(Synthesizer):
-    """MAX_VOICES copies of a voice, allocated round robin; note-offs go to every
-    voice currently playing that pitch; output = sum of the active voices /
-    MAX_VOICES (synthesizer.py:184-219)."""
+    """MAX_VOICES copies of a voice.  A note-on goes to the next voice in turn, whatever it is
+    doing; a note-off to every voice that currently plays its pitch; the output is the sum of
+    the active voices / MAX_VOICES (synthesizer.py:184-219)."""
 
     MAX_VOICES = 24
 
     def __init__(self, voice):
         super().__init__()
         self.voices = duplicate_voice(voice, self.MAX_VOICES)
-        self.freeVoice = itertools.cycle(self.voices)
-        self.allocated = 0   # note-ons handed out so far (the cycle's position)
+        self.freeVoice = RoundRobin(self.voices)
+
+    @property
+    def allocated(self):
+        """Note-ons handed out so far."""
+        return self.freeVoice.taken
 
     def process_note(self, note):
-        if note.on:
-            next(self.freeVoice).input.push(note)
-            self.allocated += 1
-        else:
-            for voice in self.voices:
-                if voice.currentPitch == note.pitch:
-                    voice.input.push(note)
+        targets = [next(self.freeVoice)] if note.on else \
+            [voice for voice in self.voices if voice.currentPitch == note.pitch]
+        for voice in targets:
+            voice.input.push(note)
 
     def update(self):
         super().update()
-        samples = MONO_SILENCE.copy()
+        bus = MONO_SILENCE.copy()
         for voice in self.voices:
             if voice.active:
                 voice.update()
-                samples += voice.output.value
-        self.output.set_value(samples / self.MAX_VOICES)
+                bus += voice.output.value
+        self.output.set_value(bus / self.MAX_VOICES)
+
+
+INTERVAL = DT * BUFFER_SIZE     # seconds per buffer
 
 
 def sample_exponential_decay(decay, t0=0.):
-    """exp(-PI / decay * (t0 + T)) as amplitude-at-t0 times the curve over one buffer, and
-    the next start time (synthesizer.py:22-36)."""
-    amp = math.exp(-PI / decay * t0)
-    return amp * np.exp(-PI / decay * T), t0 + DT * BUFFER_SIZE
+    """One buffer of exp(-PI / decay * t) starting at time `t0`, and the time the next buffer
+    starts at.  Evaluated as the reference does (synthesizer.py:22-36): the value at t0
+    (libm) times the curve over the buffer's own time vector (NumPy)."""
+    rate = -PI / decay
+    return math.exp(rate * t0) * np.exp(rate * T), t0 + INTERVAL
 
 
 def sample_pitch_decay(frequency, decay, intensity, t0=0.):
-    """synthesizer.py:39-55."""
-    env, t1 = sample_exponential_decay(decay, t0)
-    return frequency * (1. + intensity * env), t1
+    """A frequency that starts (1 + intensity) times too high and decays to `frequency`
+    (synthesizer.py:39-55)."""
+    curve, t1 = sample_exponential_decay(decay, t0)
+    return frequency * (1. + intensity * curve), t1
+
+
+class WhiteNoise:
+    """Buffers of uniform noise in [-1, 1) from NumPy's GLOBAL RandomState (the stream the
+    reference draws from, so a seeded run reproduces it): a fresh buffer per call, or -- with
+    `looped` -- one buffer drawn at construction and repeated."""
+
+    def __init__(self, looped=False):
+        self.frozen = self.draw() if looped else None
+
+    @staticmethod
+    def draw():
+        return 2 * np.random.random(BUFFER_SIZE) - 1.
+
+    def __call__(self):
+        return self.draw() if self.frozen is None else self.frozen
 
 
 class HiHat(Block):
-    """White noise under a decay envelope (synthesizer.py:222-250).  The noise is drawn from
-    NumPy's global RandomState once per buffer (or once for good with ``loopedNoise``), in the
-    reference's order: construction first, then one draw per update."""
+    """White noise under a decay envelope (synthesizer.py:222-250); any note that arrives
+    goes to the envelope.  Random numbers are drawn in the reference's order: the looped
+    buffer at construction, otherwise one buffer per update."""
 
     def __init__(self, decay=.05, loopedNoise=False):
         from klang_amd.audio.envelopes import D
         super().__init__(nOutputs=1)
         self.inputs = [MessageInput(self)]
-        if loopedNoise:
-            noise = 2 * np.random.random(BUFFER_SIZE) - 1.
-            self.noise_generator = lambda: noise
-        else:
-            self.noise_generator = lambda: 2 * np.random.random(BUFFER_SIZE) - 1.
+        self.noise_generator = WhiteNoise(looped=loopedNoise)
         self.envelope = D(decay)
 
     def update(self):
         for note in self.input.receive():
             self.envelope.input.push(note)
         self.envelope.update()
-        env = self.envelope.output.get_value()
-        self.output.set_value(env * self.noise_generator())
+        self.output.set_value(self.envelope.output.get_value() * self.noise_generator())
 
 
 class Kick(Block):
@@ -197,19 +239,19 @@ class Kick(Block):
 
     def __init__(self, frequency=40., decay=.8, intensity=2, pitchDecay=.3):
         super().__init__(nInputs=0, nOutputs=1)
-        self.frequency, self.decay = frequency, decay
-        self.intensity, self.pitchDecay = intensity, pitchDecay
         self.inputs = [MessageInput(self)]
-        self.currentTime = 0.
-        self.currentPhase = 0.
+        self.frequency, self.intensity = frequency, intensity
+        self.decay, self.pitchDecay = decay, pitchDecay
+        self.restart()
+
+    def restart(self):
+        self.currentTime, self.currentPhase = 0., 0.
 
     def update(self):
-        for note in self.input.receive():
-            if note.pitch > 0 and note.on:
-                self.currentTime = 0.
-                self.currentPhase = 0.
-        frequency, _ = sample_pitch_decay(self.frequency, self.pitchDecay, self.intensity,
-                                          self.currentTime)
-        env, self.currentTime = sample_exponential_decay(self.decay, self.currentTime)
-        signal, self.currentPhase = sample_wave(frequency, startPhase=self.currentPhase)
-        self.output.set_value(env * signal)
+        if any(note.on and note.pitch > 0 for note in list(self.input.receive())):
+            self.restart()
+        now = self.currentTime
+        sweep, _ = sample_pitch_decay(self.frequency, self.pitchDecay, self.intensity, now)
+        loudness, self.currentTime = sample_exponential_decay(self.decay, now)
+        tone, self.currentPhase = sample_wave(sweep, startPhase=self.currentPhase)
+        self.output.set_value(loudness * tone)

@@ -1,71 +1,88 @@
 """Block base class and the ``|`` / ``+`` patching operators.
 
-Host-side restatement of klang/block.py:24-238.  ``a | b`` connects a's first
-output to b's first input and returns b's owner; ``a + b`` returns a Mixer fed
-by both.  AttributeError for a missing first input/output and TypeError for
-wrong operand kinds, as in the reference (tests/test_block.py there).
+The reference's protocol (klang/block.py:24-238), which patches and the scheduler rely on:
+a block owns lists of inputs and outputs and an ``update()`` called once per 256-sample
+buffer; ``a | b`` connects a's first output to b's first input and returns b's owner;
+``a + b`` returns a Mixer fed by both; AttributeError for a missing first input / output,
+TypeError for operands that cannot be patched.  Everything about a block's surroundings is
+derived from one walk over the connections that cross its border (``border``).
 """
 from klang_amd.wiring import InputBase, OutputBase, Input, Output
+
+INWARD, OUTWARD = 'in', 'out'
+
+
+def border(block):
+    """Every connection between `block` and another block, as (direction, source output,
+    destination input): inputs first, then outputs, each in port order."""
+    crossing = []
+    for port in block.inputs:
+        source = port.incomingConnection
+        if source is not None and source.owner is not block:
+            crossing.append((INWARD, source, port))
+    for port in block.outputs:
+        crossing.extend((OUTWARD, port, sink) for sink in port.outgoingConnections
+                        if sink.owner is not block)
+    return crossing
+
+
+def _pairs(block, direction):
+    return [(src, dst) for way, src, dst in border(block) if way == direction]
 
 
 def input_connections(block):
     """(source output, input) pairs feeding `block` from other blocks."""
-    for inp in block.inputs:
-        src = inp.incomingConnection
-        if src is not None and src.owner is not block:
-            yield src, inp
+    return iter(_pairs(block, INWARD))
 
 
 def output_connections(block):
     """(output, destination input) pairs leaving `block` towards other blocks."""
-    for out in block.outputs:
-        for dst in out.outgoingConnections:
-            if dst.owner is not block:
-                yield out, dst
+    return iter(_pairs(block, OUTWARD))
 
 
 def collect_connections(block):
-    yield from input_connections(block)
-    yield from output_connections(block)
+    return ((src, dst) for _, src, dst in border(block))
 
 
 def input_neighbors(block):
-    for src, _ in input_connections(block):
-        if src.owner:
-            yield src.owner
+    """Owners of the outputs that feed `block` (ownerless endpoints have none)."""
+    return (src.owner for src, _ in _pairs(block, INWARD) if src.owner)
 
 
 def output_neighbors(block):
-    for _, dst in output_connections(block):
-        if dst.owner:
-            yield dst.owner
+    return (dst.owner for _, dst in _pairs(block, OUTWARD) if dst.owner)
+
+
+def _first_port(thing, which):
+    """A block stands for its first input / output; an endpoint for itself."""
+    return getattr(thing, which) if isinstance(thing, Block) else thing
 
 
 def fetch_input(thing):
-    return thing.input if isinstance(thing, Block) else thing
+    return _first_port(thing, 'input')
 
 
 def fetch_output(thing):
-    return thing.output if isinstance(thing, Block) else thing
+    return _first_port(thing, 'output')
 
 
 def pipe_operator(left, right):
     """left.output -> right.input; returns the owner of the input (block.py:113-132)."""
-    out, inp = fetch_output(left), fetch_input(right)
-    if not isinstance(out, OutputBase) or not isinstance(inp, InputBase):
+    source, sink = fetch_output(left), fetch_input(right)
+    if not (isinstance(source, OutputBase) and isinstance(sink, InputBase)):
         raise TypeError('Can not pipe from %s to %s' % (left, right))
-    out.connect(inp)
-    return inp.owner
+    source.connect(sink)
+    return sink.owner
 
 
 def mix_operator(left, right):
     """New Mixer over two audio outputs (block.py:135-156)."""
-    if not isinstance(fetch_output(left), Output) or not isinstance(fetch_output(right), Output):
-        raise TypeError('Can not mix %s with %s' % (left, right))
     from klang_amd.audio.mixers import Mixer
+    if not all(isinstance(fetch_output(side), Output) for side in (left, right)):
+        raise TypeError('Can not mix %s with %s' % (left, right))
     mixer = Mixer(nInputs=0)
-    mixer += left
-    mixer += right
+    for side in (left, right):
+        mixer += side
     return mixer
 
 
@@ -74,43 +91,31 @@ class Block:
     256-sample buffer (block.py:159-238)."""
 
     def __init__(self, nInputs=0, nOutputs=0, name=''):
+        self.name = name
         self.inputs = [Input(owner=self) for _ in range(nInputs)]
         self.outputs = [Output(owner=self) for _ in range(nOutputs)]
-        self.name = name
 
-    @property
-    def nInputs(self):
-        return len(self.inputs)
+    nInputs = property(lambda self: len(self.inputs))
+    nOutputs = property(lambda self: len(self.outputs))
 
-    @property
-    def nOutputs(self):
-        return len(self.outputs)
+    def _first(self, kind):
+        ports = getattr(self, kind)
+        if not ports:
+            raise AttributeError('%s has no %s!' % (self, kind))
+        return ports[0]
 
-    @property
-    def input(self):
-        if not self.inputs:
-            raise AttributeError('%s has no inputs!' % self)
-        return self.inputs[0]
-
-    @property
-    def output(self):
-        if not self.outputs:
-            raise AttributeError('%s has no outputs!' % self)
-        return self.outputs[0]
+    input = property(lambda self: self._first('inputs'))
+    output = property(lambda self: self._first('outputs'))
 
     def update(self):
         """Called once per buffer by the scheduler."""
 
     def __str__(self):
-        bits = []
-        if self.name:
-            bits.append('name: %r' % self.name)
-        if self.inputs:
-            bits.append('%d inputs' % len(self.inputs))
-        if self.outputs:
-            bits.append('%d outputs' % len(self.outputs))
-        return '%s(%s)' % (type(self).__name__, ', '.join(bits))
+        facts = [('name: %r', self.name), ('%d inputs', len(self.inputs)),
+                 ('%d outputs', len(self.outputs))]
+        return '%s(%s)' % (type(self).__name__, ', '.join(fmt % val for fmt, val in facts if val))
 
+    # patching operators, both operand orders (an endpoint on the left reaches __r*__)
     def __or__(self, other):
         return pipe_operator(self, other)
 

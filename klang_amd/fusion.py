@@ -395,7 +395,6 @@ class GpuVoiceBank(Block):
                     bank.note(i, 0, note.pitch, note.velocity, note.frequency)
                     if note.on:
                         next(syn.freeVoice)
-                        syn.allocated += 1
                 else:
                     syn.process_note(note)              # NoteScheduler -> voice.input
         for i, c in enumerate(self.chains):
@@ -474,7 +473,6 @@ class GpuVoiceBank(Block):
                 self.bank.note(i, block, note.pitch, note.velocity, note.frequency)
                 if note.on:
                     next(syn.freeVoice)
-                    syn.allocated += 1
                 return
             note = syn.noteScheduler.get_next_note(note)    # MonophonicSynthesizer.process_note
         voice = self.chains[i].voice

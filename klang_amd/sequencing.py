@@ -173,40 +173,45 @@ class MicroRhyhtm(Block):
 
 def random_pattern(length, period=None, minVal=60, maxVal=72):
     """`length` random pitches that repeat every `period` (sequencer.py:29-53; Python's
-    `random` module, one randint per period entry)."""
+    `random` module, one randint per period entry, drawn before anything is repeated)."""
     period = length if period is None else period
-    seed = [random.randint(minVal, maxVal) for _ in range(period)]
-    return list(itertools.islice(itertools.cycle(seed), length))
+    motif = [random.randint(minVal, maxVal) for _ in range(period)]
+    return [motif[step % period] for step in range(length)]
 
 
 def pizza_slice_number(angle, nSlices):
     """Which of nSlices equal slices of the circle `angle` lies in (sequencer.py:56-66)."""
-    return int((angle % TAU) / TAU * nSlices)
+    turn = (angle % TAU) / TAU
+    return int(turn * nSlices)
 
 
-def _is_sequence(obj):
-    return isinstance(obj, collections.abc.Sequence)
+def _nested(obj, depth):
+    """`obj` wrapped in lists until it is `depth` levels of sequence deep (looking at first
+    elements only, so ragged rows stay as they are); arrays go through NumPy's own
+    atleast_*d (sequencer.py:69-93)."""
+    if isinstance(obj, np.ndarray):
+        return (np.atleast_1d, np.atleast_2d)[depth - 1](obj)
+    levels, probe = 0, obj
+    while levels < depth and isinstance(probe, collections.abc.Sequence):
+        levels += 1
+        probe = probe[0] if len(probe) else None
+    for _ in range(depth - levels):
+        obj = [obj]
+    return obj
 
 
 def atleast_1d(obj):
-    """np.atleast_1d for arrays; anything that is no sequence is packed into a list, ragged
-    lists stay as they are (sequencer.py:69-79)."""
-    if isinstance(obj, np.ndarray):
-        return np.atleast_1d(obj)
-    return obj if _is_sequence(obj) else [obj]
+    return _nested(obj, 1)
 
 
 def atleast_2d(obj):
-    """Same for two levels (sequencer.py:82-93)."""
-    if isinstance(obj, np.ndarray):
-        return np.atleast_2d(obj)
-    obj = atleast_1d(obj)
-    return obj if _is_sequence(obj[0]) else [obj]
+    return _nested(obj, 2)
 
 
 class PizzaSlicer(Block):
-    """Phase in [0, TAU) -> step numbers: sends every step index between the last one sent
-    and the one the phase is in now, wrapping around (sequencer.py:96-128)."""
+    """Phase in [0, TAU) -> step numbers.  Sends every step from the one after the last step
+    sent up to the one the phase is in now, around the circle if need be, so no step is lost
+    when the phase jumps over several (sequencer.py:96-128)."""
 
     def __init__(self, nSlices):
         super().__init__(nInputs=1)
@@ -218,10 +223,11 @@ class PizzaSlicer(Block):
         self.currentIdx = (self.currentIdx + 1) % self.nSlices
 
     def update(self):
-        target = pizza_slice_number(self.input.value, self.nSlices)
-        for _ in range((target - self.currentIdx) % self.nSlices):
+        behind = (pizza_slice_number(self.input.value, self.nSlices) - self.currentIdx) % self.nSlices
+        while behind:
             self.increment()
             self.output.send(self.currentIdx)
+            behind -= 1
 
 
 class PatternLookup(_MessageBlock):
@@ -232,17 +238,21 @@ class PatternLookup(_MessageBlock):
         super().__init__()
         self.pattern = pattern
 
+    def pitches(self, step):
+        return [pitch for pitch in atleast_1d(self.pattern[step]) if pitch]
+
     def update(self):
         for step in self.input.receive():
-            for pitch in atleast_1d(self.pattern[step]):
-                if pitch:
-                    self.output.send(Note(pitch=pitch, velocity=1.))
+            for pitch in self.pitches(step):
+                self.output.send(Note(pitch=pitch, velocity=1.))
 
 
 class Sequence(Composite):
-    """One sequencer channel: Phasor -> (phase insert) -> PizzaSlicer -> PatternLookup ->
-    NoteLengthener (sequencer.py:154-243).  The phase leaves through `phaseOut` and comes back
-    through `phaseIn`, so that a micro rhythm can be patched in between."""
+    """One sequencer channel (sequencer.py:154-243): a Phasor turns once per pattern, a
+    PizzaSlicer cuts the turn into steps, a PatternLookup turns steps into notes and a
+    NoteLengthener ends them.  Between phasor and slicer the phase leaves the composite
+    through `phaseOut` and comes back through `phaseIn` -- normally straight, or through a
+    micro rhythm patched in between."""
 
     def __init__(self, sequencer, pattern, tempo=120, beatValue=QUARTER_NOTE,
                  grid=SIXTEENTH_NOTE, relNoteLength=.5, absNoteLength=None):
@@ -250,51 +260,63 @@ class Sequence(Composite):
         self.sequencer = sequencer
         self.pattern = atleast_1d(pattern)
         self.tempo, self.beatValue, self.grid = tempo, beatValue, grid
-        self.phaseIn = Relay(owner=self)
-        self.phaseOut = Relay(owner=self)
+        noteLength = absNoteLength
+        if noteLength is None:
+            noteLength = relNoteLength * self.duration / self.length
+        # ports
+        self.phaseIn, self.phaseOut = Relay(owner=self), Relay(owner=self)
         self.inputs = [self.phaseIn]
         self.outputs = [MessageRelay(owner=self), self.phaseOut]
-        if absNoteLength is None:
-            absNoteLength = relNoteLength * self.duration / self.length
+        # inner blocks, in signal order
         self.phasor = Phasor(frequency=1. / self.duration)
         self.pizza = PizzaSlicer(self.length)
         self.lookup = PatternLookup(self.pattern)
-        self.lengthener = NoteLengthener(absNoteLength)
+        self.lengthener = NoteLengthener(noteLength)
         self.phasor | self.phaseOut
-        self.phaseOut.connect(self.phaseIn)
-        self.phaseIn | self.pizza | self.lookup | self.lengthener | self.output
+        self._bridge()
+        stage = self.phaseIn
+        for nxt in (self.pizza, self.lookup, self.lengthener, self.output):
+            stage = stage | nxt
         self.update_internal_exec_order(self.phasor, self.pizza)
 
-    @property
-    def length(self):
-        return len(self.pattern)
+    length = property(lambda self: len(self.pattern))
 
     @property
     def duration(self):
         """Seconds one pass through the pattern takes."""
-        return self.length * self.grid / self.beatValue * tempo_2_period(self.tempo)
+        beats = self.length * self.grid / self.beatValue
+        return beats * tempo_2_period(self.tempo)
+
+    def _bridge(self):
+        """phaseOut straight into phaseIn."""
+        self.phaseOut.connect(self.phaseIn)
 
     def disconnect_phase_insert(self):
-        for dst in set(self.phaseOut.outgoingConnections):
-            self.phaseOut.disconnect(dst)
-        if self.phaseIn.connected:
-            self.phaseIn.incomingConnection.disconnect(self.phaseIn)
+        """Whatever sits between phaseOut and phaseIn is taken out on both sides."""
+        for sink in list(self.phaseOut.outgoingConnections):
+            self.phaseOut.disconnect(sink)
+        source = self.phaseIn.incomingConnection
+        if source is not None:
+            source.disconnect(self.phaseIn)
+
+    def _reorder(self):
+        self.sequencer.update_internal_exec_order()
 
     def apply_micro_rhythm(self, microRhythm):
         self.disconnect_phase_insert()
         self.phaseOut | microRhythm | self.phaseIn
-        self.sequencer.update_internal_exec_order()
+        self._reorder()
 
     def reset_micro_rhythm(self):
         self.disconnect_phase_insert()
-        self.phaseOut.connect(self.phaseIn)
-        self.sequencer.update_internal_exec_order()
+        self._bridge()
+        self._reorder()
 
 
 class Sequencer(Composite):
-    """Pattern sequencer: one Sequence per pattern row, each on an output of its own, or all
-    through one MessageMixer with splitOutputs=False (sequencer.py:246-301).  Further
-    arguments go to every Sequence."""
+    """Pattern sequencer (sequencer.py:246-301): one Sequence per pattern row.  With
+    splitOutputs every row sends on a message output of its own; without, all rows go
+    through one MessageMixer to a single output.  Further arguments go to every Sequence."""
 
     def __init__(self, pattern, *args, splitOutputs=True, **kwargs):
         super().__init__()
@@ -302,27 +324,27 @@ class Sequencer(Composite):
         self.splitOutputs = splitOutputs
         self.sequences = []
         if not splitOutputs:
-            self.msgMixer = MessageMixer(nInputs=0)
             self.outputs = [MessageRelay(owner=self)]
+            self.msgMixer = MessageMixer(nInputs=0)
             self.msgMixer | self.output
         for row in self.pattern:
             self.add_new_channel(row, *args, **kwargs)
 
-    def add_new_channel(self, *args, **kwargs):
-        seq = Sequence(self, *args, **kwargs)
-        self.sequences.append(seq)
+    def _sink_for_new_row(self):
+        """Where the next row's notes go: a new output relay, or a new mixer input."""
         if self.splitOutputs:
-            relay = MessageRelay(owner=self)
-            self.outputs.append(relay)
-            seq | relay
-        else:
-            self.msgMixer.add_new_channel()
-            seq | self.msgMixer.inputs[-1]
+            self.outputs.append(MessageRelay(owner=self))
+            return self.outputs[-1]
+        self.msgMixer.add_new_channel()
+        return self.msgMixer.inputs[-1]
+
+    def add_new_channel(self, *args, **kwargs):
+        row = Sequence(self, *args, **kwargs)
+        self.sequences.append(row)
+        row | self._sink_for_new_row()
         self.update_internal_exec_order()
 
-    @property
-    def nChannels(self):
-        return len(self.pattern)
+    nChannels = property(lambda self: len(self.pattern))
 
     def apply_micro_rhythm(self, microRhythm, channel):
         self.sequences[channel].apply_micro_rhythm(microRhythm)
