@@ -37,7 +37,8 @@ def _adjacency(n_nodes, edges):
     succ = [set() for _ in range(n_nodes)]
     for a, b in edges:
         succ[a].add(b)
-    return [sorted(s) for s in succ]
+    # (most nodes of a large patch have one successor: nothing to sort)
+    return [sorted(s) if len(s) > 1 else list(s) for s in succ]
 
 
 def find_back_edges(n_nodes, edges):

@@ -548,3 +548,44 @@ def test_prescheduled_mono_synths_and_kick_render_ahead(hip):
     # live (buffer by buffer) on the device gives the same samples as prescheduled
     live = np.concatenate(run_klang(dm.build(), offline=True, duration=dur, lookahead=1))
     assert np.abs(live - got).max() <= 1e-7
+
+
+def test_api_patch_at_baseline_size_equals_the_cabi_bank(hip, tmp_path):
+    """BASELINE configs[2] through the drop-in API: 65,536 Voice(Oscillator, ADSR) | Filter
+    chains built block by block into one Mixer | Dac, run_klang(filepath=...) on the device --
+    against the C-ABI bank loaded with the same patch (klang.py:59-90)."""
+    import time
+    n, nb = 65536, 6
+    p = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=2, off_span=3)
+    t0 = time.perf_counter()
+    mixer = Mixer()
+    voices = []
+    for v in range(n):
+        voice = Voice(Oscillator(wave_func=sawtooth),
+                      ADSR(p.attack[v], p.decay[v], p.sustain[v], p.release[v]))
+        fil = Filter(frequency=p.cutoff[v])
+        voice | fil
+        mixer += fil
+        voice.input.push(Note(0, p.velocity[v], frequency=p.frequency[v]))
+        voices.append(voice)
+    dac = mixer | Dac()
+    t1 = time.perf_counter()
+    # note-offs are not part of this comparison: the notes above are all the patch gets
+    path = str(tmp_path / 'baseline.wav')
+    frames = run_klang(dac, filepath=path, offline=True, duration=nb * B / 44100. + 1e-9, fadeout=0.)
+    t2 = time.perf_counter()
+    got = np.concatenate(frames)[:, 0].reshape(nb, B)
+    ctx = hip.Context(0)
+    bank = hip.Bank(ctx, n, has_env=True, has_filter=True)
+    q = P.Patch(p)
+    q['events'] = p.events[p.events['kind'] == P.EV_NOTE_ON]
+    bank.load_patch(q)
+    want = bank.render(nb)[:, 0, :]
+    ctx.close()
+    assert np.abs(want).max() > 1e-4
+    err = np.abs(got - want).max()
+    report('API patch, 65,536 chains, vs the C-ABI bank', err)
+    assert err <= 1e-6
+    with wave.open(path, 'rb') as wav:
+        assert wav.getnframes() == nb * B
+    print('api 65,536 chains: build %.1f s, run_klang %.1f s' % (t1 - t0, t2 - t1))

@@ -11,7 +11,7 @@ import numpy as np
 from klang_amd.audio import ADSR, Dac, Filter, Mixer, Oscillator, Voice, sawtooth
 from klang_amd.klang import run_klang
 from klang_amd.messages import Note
-for n in (1024, 8192):
+for n in (1024, 8192, 65536):
     rng = np.random.default_rng(0)
     t0 = time.perf_counter()
     mixer = Mixer()
