@@ -313,6 +313,14 @@ int klmi_bank_set_mix_divisor(klmi_bank *bank, double divisor);
  * one input); previews read from the current position without consuming. */
 int klmi_bank_set_input(klmi_bank *bank, const double *host_x, int n_blocks);
 
+/* The same from the device: the first n_blocks buffers `source` mixed in its last
+ * klmi_bank_render (they are still in its device bus) become this bank's external input;
+ * voice v listens to channel v % channels of that bus.  It replaces the per-buffer hop
+ * Output.value -> Input.value between two fused groups of blocks (connections.py:274-302),
+ * e.g. `mixer | Reverb | Dac` (examples/reverberation_demo.py:33-34): both banks can then
+ * render many buffers per call.  Same context (GPU) for both banks. */
+int klmi_bank_set_input_from_bank(klmi_bank *bank, klmi_bank *source, int n_blocks);
+
 /* THE hot call.  Renders n_blocks buffers of every voice, advances all state,
  * consumes due events, writes the mix bus [n_blocks][channels][256] float32
  * (channels = stereo ? 2 : 1).  _device writes to a device pointer and does

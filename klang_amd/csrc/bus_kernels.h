@@ -50,6 +50,19 @@ __global__ void bus_finish_kernel(const double *__restrict__ stage, int slices, 
     bus[s] = (float)(acc / divisor);
 }
 
+// A mix bus [blocks][channels][256] float32 as the external input [span][n] float64 of
+// another bank (klmi_bank_set_input_from_bank): voice v listens to channel v % channels.
+__global__ void bus_to_input_kernel(const float *__restrict__ mix, int channels, int n,
+                                    size_t span, double *__restrict__ ext)
+{
+    const size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= span)
+        return;
+    const size_t block = s / 256, i = s % 256;
+    for (int v = 0; v < n; ++v)
+        ext[s * n + v] = (double)mix[(block * channels + (size_t)(v % channels)) * 256 + i];
+}
+
 // Streaming probes for klmi_ctx_stream_rate: what this GPU's memory system gives a plain
 // hand-written kernel, as the yardstick for the HBM-bound kernels.  One 16-byte access per
 // lane, one workgroup per 4 KiB, workgroups dispatched in address order: the shape that

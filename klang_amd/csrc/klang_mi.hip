@@ -509,6 +509,7 @@ struct klmi_bank {
     DevBuf<float> partial, dev_mix, dev_voices_f32;
     DevBuf<double> stage;  // bus reduction, slice sums
     DevBuf<double> dev_voices_f64, ext_input, bus_f64;
+    int last_mix_blocks = 0;  // blocks of the last klmi_bank_render, still in dev_mix
     int ext_blocks = 0;   // blocks supplied by klmi_bank_set_input
     int ext_cursor = 0;   // blocks of it consumed by renders so far
 
@@ -1631,10 +1632,38 @@ extern "C" int klmi_bank_render(klmi_bank *b, int n_blocks, float *host_mix)
         return fail(KLMI_E_ARG, "klmi_bank_render: n_blocks must be positive, got %d", n_blocks);
     const size_t len = (size_t)n_blocks * (b->desc.stereo ? 2 : 1) * kBlock;
     HIP_TRY(b->dev_mix.reserve(len));
+    b->last_mix_blocks = 0;
     TRY(render_mix(b, n_blocks, b->dev_mix.p));
+    b->last_mix_blocks = n_blocks;
     HIP_TRY(hipMemcpyAsync(host_mix, b->dev_mix.p, sizeof(float) * len, hipMemcpyDeviceToHost,
                            b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+// Bank -> bank on the device: what `source` mixed in its last klmi_bank_render is this
+// bank's external input, without the way over the host.
+extern "C" int klmi_bank_set_input_from_bank(klmi_bank *b, klmi_bank *source, int n_blocks)
+{
+    if (!b || !source || b == source || n_blocks <= 0)
+        return fail(KLMI_E_ARG, "klmi_bank_set_input_from_bank: bad argument");
+    if (b->ctx != source->ctx)
+        return fail(KLMI_E_ARG, "klmi_bank_set_input_from_bank: the banks live on different contexts");
+    if (source->last_mix_blocks < n_blocks)
+        return fail(KLMI_E_STATE, "klmi_bank_set_input_from_bank: the source's last klmi_bank_render "
+                                  "left %d buffer(s), %d asked for", source->last_mix_blocks, n_blocks);
+    TRY(use(b->ctx));
+    const size_t span = (size_t)n_blocks * kBlock, n = (size_t)b->n;
+    hipStream_t st = b->ctx->stream;
+    if (b->ext_input.n < span * n) {
+        HIP_TRY(hipStreamSynchronize(st));   // nothing in flight may still read the old input
+        HIP_TRY(b->ext_input.reserve(span * n));
+    }
+    hipLaunchKernelGGL(bus_to_input_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, st,
+                       source->dev_mix.p, source->desc.stereo ? 2 : 1, b->n, span, b->ext_input.p);
+    HIP_TRY(hipGetLastError());
+    b->ext_blocks = n_blocks;
+    b->ext_cursor = 0;
     return 0;
 }
 
@@ -1753,7 +1782,9 @@ static int bounce_device(klmi_bank *b, int n_blocks, double duration, double fad
     const int ch = b->desc.stereo ? 2 : 1;
     const size_t len = (size_t)n_blocks * ch * kBlock;
     HIP_TRY(b->dev_mix.reserve(len));
+    b->last_mix_blocks = 0;
     TRY(render_mix(b, n_blocks, b->dev_mix.p));
+    b->last_mix_blocks = n_blocks;
     // playTime += INTERVAL, a running float64 sum (klanggeber.py:199, 248)
     std::vector<double> play_time(n_blocks);
     double t = 0.;

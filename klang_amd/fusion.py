@@ -271,6 +271,10 @@ class GpuVoiceBank(Block):
         if self.pairs:
             self.bank.set_mix_divisor(float(max(1, len(chains) // 2)) if len(chains) > 2 else 1.)
             self._pair_state = None
+        self.upstream = None    # the mono bank whose bus feeds this bank's single chain, when
+                                # there is one (compile_order): its buffers then arrive device
+                                # to device and both banks render ahead in lock-step
+        self._fresh = 0         # buffers of the last render() a downstream bank may still take
         self._twins = []        # banks for channels 1.. of a chain fed with a multi-channel signal
         self.lookahead = 1      # blocks rendered per device call (set by run_klang)
         self.remaining = None   # buffers still to be delivered, when the caller knows (offline
@@ -437,13 +441,21 @@ class GpuVoiceBank(Block):
                              'use lookahead=1 for patches with live message sources')
         if not self._ready:
             self._collect_events()
-            if self.external:
-                self._feed_external()
+            chained = self.upstream is not None and self.upstream._fresh > 0
             # float32 [n][channels][256] -> per buffer (256,) mono or (2, 256) stereo
-            ahead = 1 if self.external else max(1, int(self.lookahead))
+            ahead = 1 if (self.external and not chained) else max(1, int(self.lookahead))
             if self.remaining is not None:
                 ahead = max(1, min(ahead, int(self.remaining)))
+            if chained:
+                # the upstream bank has just rendered its next buffers (it runs first and keeps
+                # the same pace): they come over on the device
+                ahead = min(ahead, self.upstream._fresh)
+                self.bank.set_input_from(self.upstream.bank, ahead)
+                self.upstream._fresh = 0
+            elif self.external:
+                self._feed_external()
             mix = self.bank.render(ahead)
+            self._fresh = ahead
             self._ready = [blk if self.stereo else blk[0] for blk in mix][::-1]
         if self.remaining is not None:
             self.remaining -= 1
@@ -544,6 +556,20 @@ class GpuVoiceBank(Block):
                                  '%s from %s' % (self, BUFFER_SIZE, value.shape, c.external.owner))
             rows.append(value)
         self.bank.set_input(np.stack(rows))
+
+    def render_for(self, downstream, n_blocks):
+        """The whole piece for a bank that listens to this one's bus, device to device."""
+        if self._ready or downstream._ready:
+            raise KlangError('GpuVoiceBank.render_for: buffers were already rendered ahead')
+        self._collect_events()
+        if self.external and self.upstream is None:
+            raise KlangError('GpuVoiceBank.render_for: %s is fed from the host' % self)
+        mix = self.bank.render(n_blocks)
+        downstream.bank.set_input_from(self.bank, n_blocks)
+        if self.remaining is not None:
+            self.remaining = 0
+        last = mix[-1].astype(np.float64)
+        self.sink.output.set_value(last if self.stereo else last[0])
 
     def bounce(self, duration, fadeout=0., want_pcm=True):
         """The whole piece in one device pass (klmi_bank_bounce): notes queued so far are
@@ -882,6 +908,28 @@ def find_fusable(exec_order):
     return groups, errors
 
 
+CHAIN_ON_DEVICE = True   # tests switch it off to get the per-buffer host hop to compare with
+
+
+def link_banks(order):
+    """Bank -> bank on the device.  A bank whose single chain listens to the mono bus of
+    another bank (`mixer | Reverb | Dac`, effects after a synthesizer) takes that bus device
+    to device (klmi_bank_set_input_from_bank) when the upstream bank runs before it, on the
+    same context, and nobody else needs the buffers in between."""
+    if not CHAIN_ON_DEVICE:
+        return
+    banks = [b for b in order if isinstance(b, GpuVoiceBank)]
+    by_output = {id(b.sink.output): b for b in banks}
+    for k, bank in enumerate(banks):
+        if not bank.external or bank.pairs or len(bank.chains) != 1:
+            continue
+        source = by_output.get(id(bank.chains[0].external))
+        if (source is None or source is bank or source.stereo or source.ctx is not bank.ctx
+                or source not in banks[:k] or source._twins):
+            continue
+        bank.upstream = source
+
+
 def compile_order(exec_order, ctx=None, strict=True):
     """Replace fusable chains in `exec_order` by GpuVoiceBank blocks.  With
     strict=True every hot-path block must end up fused (KlangError otherwise)."""
@@ -908,6 +956,7 @@ def compile_order(exec_order, ctx=None, strict=True):
             new_order.append(banks_at[blk])
         elif blk not in fused_blocks:
             new_order.append(blk)
+    link_banks(new_order)
     if strict:
         left = [b for b in _flat(new_order) if isinstance(b, HOT_PATH_TYPES)
                 and type(b) not in (Phasor, Lfo)]

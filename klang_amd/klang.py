@@ -49,18 +49,23 @@ def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', of
     if not offline or duration == INF or adc.nChannels:
         return None
     banks = [b for b in execOrder if isinstance(b, fusion.GpuVoiceBank)]
-    if len(banks) != 1 or any(b is not banks[0] and b is not dac for b in execOrder):
+    if not banks or any(b not in banks and b is not dac for b in execOrder):
         return None
-    bank = banks[0]
-    if bank.external:
+    # one bank, or a chain of banks each fed by the one before it on the device
+    # (`mixer | Reverb | Dac`): the upstream banks render the whole piece, the last one bounces
+    bank = banks[-1]
+    if banks[0].external or any(b.upstream is not a for a, b in zip(banks, banks[1:])):
+        return None
+    n_cycles = int(duration * SAMPLING_RATE // BUFFER_SIZE)
+    if n_cycles < 1:
         return None
     feeds = [i.incomingConnection for i in dac.inputs if i.incomingConnection is not None]
     if (feeds != [bank.sink.output] or dac.inputs[0].incomingConnection is None
             or bank.bank.channels != dac.nChannels):
         return None
-    if int(duration * SAMPLING_RATE // BUFFER_SIZE) < 1:
-        return None
     try:
+        for upstream, downstream in zip(banks, banks[1:]):
+            upstream.render_for(downstream, n_cycles)
         frames, pcm = bank.bounce(duration, fadeout, want_pcm=bool(filepath))
     except native.NativeError as err:
         if err.code == native.E_ARG and 'Zero amplitude' in str(err):

@@ -60,7 +60,7 @@ EXPORTS = [
     'klmi_envelope_coefficients', 'klmi_low_pass_coefficients', 'klmi_panning_amplitudes', 'klmi_reverb_design',
     'klmi_bank_create', 'klmi_bank_destroy', 'klmi_bank_set_params', 'klmi_bank_state_get',
     'klmi_bank_state_set', 'klmi_bank_events', 'klmi_bank_notes',
-    'klmi_bank_set_mix_divisor', 'klmi_bank_set_input',
+    'klmi_bank_set_mix_divisor', 'klmi_bank_set_input', 'klmi_bank_set_input_from_bank',
     'klmi_bank_render', 'klmi_bank_render_device', 'klmi_bank_render_device_noalloc',
     'klmi_bank_render_voices',
     'klmi_bank_render_voices_f64', 'klmi_bank_render_voices_device', 'klmi_bank_reverb_state_get',
@@ -132,6 +132,7 @@ def load():
     L.klmi_bank_notes.argtypes = [_vp, _vp, C.c_size_t]
     L.klmi_bank_set_mix_divisor.argtypes = [_vp, C.c_double]
     L.klmi_bank_set_input.argtypes = [_vp, _dp, C.c_int]
+    L.klmi_bank_set_input_from_bank.argtypes = [_vp, _vp, C.c_int]
     L.klmi_bank_render.argtypes = [_vp, C.c_int, _fp]
     L.klmi_bank_render_device.argtypes = [_vp, C.c_int, _vp]
     L.klmi_bank_render_device_noalloc.argtypes = [_vp, C.c_int, _vp]
@@ -416,6 +417,11 @@ class Bank:
         x = _f64(x).reshape(self.n, -1)
         assert x.shape[1] % BUFFER_SIZE == 0
         _check(load().klmi_bank_set_input(self._h, _p(x), x.shape[1] // BUFFER_SIZE))
+
+    def set_input_from(self, source, n_blocks):
+        """The first n_blocks buffers of `source`'s last render() as this bank's external
+        input, device to device (klmi_bank_set_input_from_bank)."""
+        _check(load().klmi_bank_set_input_from_bank(self._h, source._h, int(n_blocks)))
 
     def render(self, n_blocks):
         """-> float32 [n_blocks][channels][256]; advances state, consumes events."""

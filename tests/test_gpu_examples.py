@@ -95,3 +95,30 @@ def test_aeolian_arp_leaves_no_note_source_on_the_host(hip):
                          'Dac'}, left
     for bank in banks:
         bank.close()
+
+
+def test_banks_are_chained_on_the_device(hip, monkeypatch):
+    """`mixer | Reverb | Dac` (examples/reverberation_demo.py:33-34 of the reference): the
+    synthesizers' bank and the Reverb's bank are linked device to device, so the offline
+    bounce is one device pass over both (klmi_bank_set_input_from_bank + klmi_bank_bounce)
+    and equals the per-buffer evaluation in which every buffer crosses the host."""
+    from examples import reverberation_demo
+    from klang_amd import fusion
+    from klang_amd.schedule import determine_execution_order
+    order, banks = fusion.compile_order(determine_execution_order([reverberation_demo.build()]))
+    device = [b for b in order if isinstance(b, fusion.GpuVoiceBank)]
+    assert len(device) == 2 and device[1].upstream is device[0] and device[0].upstream is None
+    for bank in banks:
+        bank.close()
+    calls = []
+    real = fusion.GpuVoiceBank.bounce
+    monkeypatch.setattr(fusion.GpuVoiceBank, 'bounce',
+                        lambda self, *a, **k: calls.append(self) or real(self, *a, **k))
+    fast = np.concatenate(run_klang(reverberation_demo.build(), offline=True, duration=2.4, fadeout=.2))
+    assert len(calls) == 1 and calls[0].upstream is not None      # one pass, end to end
+    # buffers rendered ahead in lock-step (no bounce: lookahead given, engine loop on the host)
+    monkeypatch.setattr(fusion.GpuVoiceBank, 'bounce', real)
+    monkeypatch.setattr(fusion, 'CHAIN_ON_DEVICE', False)
+    slow = np.concatenate(run_klang(reverberation_demo.build(), offline=True, duration=2.4, fadeout=.2))
+    assert fast.shape == slow.shape and np.abs(slow).max() > .02
+    assert report('bank -> bank on the device vs per-buffer host hop', np.abs(fast - slow).max()) <= 1e-7
