@@ -102,8 +102,23 @@ class Chain:
             if stage.frequency.connected:
                 self.cutoff_lfo = self._private_lfo(stage.frequency, SCALAR, '%s.frequency' % stage)
             self.filter = stage
-        elif any(i.connected for i in stage.inputs if i is not stage.input):
-            raise NotFusable('%s: its parameter inputs are patched (modulated)' % stage)
+        else:
+            # A patched parameter input (an Lfo into Tremolo.rate, Gain.gain ...) is followed
+            # at block rate: the source stays a host block, runs before the bank, and the
+            # value it holds at each buffer is uploaded like a host-side edit
+            # (GpuVoiceBank._upload_stage).  Only sources the host evaluates, with one value
+            # per buffer, qualify.
+            for inp in stage.inputs:
+                if inp is stage.input or not inp.connected:
+                    continue
+                source = inp.incomingConnection.owner
+                if type(source) in EFFECT_KINDS or isinstance(source, (Voice, Reverb, Oscillator)):
+                    raise NotFusable('%s: a parameter input is fed at audio rate by %s'
+                                     % (stage, source))
+                if np.ndim(inp.value) != 0:
+                    raise NotFusable('%s: a parameter input carries an array per buffer '
+                                     '(audio-rate modulation of effect parameters is not fused)'
+                                     % stage)
         if kind is RingModulator:
             if stage.lfo.wave_func not in WAVE_IDS or WAVE_IDS[stage.lfo.wave_func] > native.WAVE_TRIANGLE:
                 raise NotFusable('%s: Lfo wave function %r has no device twin'

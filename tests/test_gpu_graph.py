@@ -290,16 +290,34 @@ def _effect_patches():
                       | Reverb(decay=1., dryWet=.5))
         return mixer | Dac()
 
+    def patched_parameters():  # effect parameters driven at block rate by host Lfos
+        # (effects.py:67-70, 117-133: Gain.gain, Tremolo.rate / depth are value inputs)
+        mixer = Mixer()
+        for k in range(3):
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+            voice.input.push(Note(0, .8, frequency=98. * (k + 1)))
+            trem, gain = Tremolo(rate=4., depth=.5, smoothness=.4), Gain(.5)
+            Lfo(frequency=.7 + k, outputRange=(2., 9.)) | trem.rate
+            Lfo(frequency=1.3, wave_func=triangle, outputRange=(.2, .9)) | trem.depth
+            Lfo(frequency=2. + k, outputRange=(.1, 1.)) | gain.gain
+            mixer += voice | Filter(frequency=900.) | trem | gain
+        return mixer | Dac()
+
     return dict(arpeggiator_like=arpeggiator_like, tremolo_chain=tremolo_chain, shaping=shaping,
-                lofi=lofi, stereo_stages=stereo_stages, stages_into_reverb=stages_into_reverb)
+                lofi=lofi, stereo_stages=stereo_stages, stages_into_reverb=stages_into_reverb,
+                patched_parameters=patched_parameters)
 
 
 @pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping', 'lofi',
-                                  'stereo_stages', 'stages_into_reverb'])
+                                  'stereo_stages', 'stages_into_reverb', 'patched_parameters'])
 def test_effect_patches_match_the_host_evaluation(hip, name):
     build = _effect_patches()[name]
     order, banks = fusion.compile_order(determine_execution_order([build()]))
-    assert [type(b).__name__ for b in order] == ['GpuVoiceBank', 'Dac']
+    names = [type(b).__name__ for b in order]
+    if name == 'patched_parameters':   # the control Lfos stay host blocks, in front of the bank
+        assert names == 9 * ['Lfo'] + ['GpuVoiceBank', 'Dac']
+    else:
+        assert names == ['GpuVoiceBank', 'Dac']
     for bank in banks:
         bank.close()
     dur = 24 * B / 44100. + 1e-9
