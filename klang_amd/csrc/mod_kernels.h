@@ -93,6 +93,60 @@ __device__ __forceinline__ void mod_tau_group(bool fast, const double (&a)[G], d
         p[j] = np_mod_tau_sel<BD>(a[j]);
 }
 
+// FmOscillator's carrier (oscillators.py:220): wave(q) for G phases q of any sign, bounded
+// (|q| < 1e9), one wave function for the whole wavefront.  The branch-free remainder
+// np_mod_tau_bounded costs three float64 compares + selects per call (quarter-rate
+// instructions: the most expensive part of the FM sample).  Here the remainder of q (sawtooth,
+// sine) or q + PI (square, triangle: math.py:9-11 wrap) is speculated as
+// r = fma(-floor(a / TAU), TAU, a) -- the same real number x - floor(x/TAU) TAU that NumPy's
+// fmod-then-sign-fix yields, rounded once, for either sign -- with ONE range check over the
+// group's high words; a quotient estimate that is off by one, or an r that rounds to TAU,
+// sends the group to the exact form.  Returns false when `sel` is not one of the four.
+template <bool BD, int G>
+__device__ __forceinline__ bool fm_wave_group(int sel, const double (&q)[G], double (&x)[G])
+{
+    if (!BD || sel < W_SINE || sel > W_TRIANGLE)
+        return false;
+    const bool shifted = sel == W_SQUARE || sel == W_TRIANGLE;
+    double r[G];
+    uint32_t hi_max = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        const double a = shifted ? q[j] + kPi : q[j];
+        const double k = floor(a * kInvTau);
+        r[j] = __builtin_fma(-k, kTau, a);
+        hi_max = max(hi_max, (uint32_t)__double2hiint(r[j]));
+    }
+    if (__builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) != 0)
+        return false;   // some lane: the exact path for the whole group
+    switch (sel) {
+    case W_SINE:
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            x[j] = sin_wrapped(r[j]);
+        break;
+    case W_SQUARE:
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            x[j] = (r[j] - kPi >= 0.) ? 1. : -1.;
+        break;
+    case W_SAWTOOTH:
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+            x[j] = div_pi(r[j]) - 1.;
+        break;
+    default:
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            double t4 = div_tau(4. * (r[j] - kPi));
+            t4 = t4 < 0. ? t4 + 4. : t4;
+            x[j] = 1. - fabs(t4 - 2.);
+        }
+        break;
+    }
+    return true;
+}
+
 // two float64 at 8-byte alignment (one 16-byte access)
 struct __attribute__((packed, aligned(8))) Double2U {
     double a, b;
@@ -413,7 +467,8 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
 #pragma unroll
                 for (int j = 0; j < G; ++j)
                     p[j] = p[j] + mod_scale * m[j];
-                wave_block<false, BD, G>(uniform_wave, wave_id, p, duty_edge, x);
+                if (!fm_wave_group<BD, G>(uniform_wave, p, x))
+                    wave_block<false, BD, G>(uniform_wave, wave_id, p, duty_edge, x);
             } else if (target == MT_DUTY) { // oscillators.py:259-260
 #pragma unroll
                 for (int j = 0; j < G; ++j)
