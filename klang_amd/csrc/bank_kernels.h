@@ -267,7 +267,13 @@ __device__ __forceinline__ void lfo_cutoff_step(const BankView &bk, int v, doubl
 // GATED (synthesizer banks, synthesizer.py:151-219): a voice is only updated in a buffer in
 // which it is active or receives a note; polyphonic banks route their instrument's notes here
 // (round robin), exactly as voice_mod_kernel does for the chains this kernel does not cover.
-template <bool ENV, bool FILT, int MODE, bool GATED = false>
+// FM: the oscillator is an FmOscillator (oscillators.py:193-234): its own Oscillator(modFrequency)
+// sampled at the same time points, and the wave function evaluated at phase + intensity *
+// modulator -- a phase of any sign.  The eight-sample region speculates one more remainder (of
+// that sum) under the same single check; wavefronts whose carrier and modulator do not share
+// one of sine / square / sawtooth / triangle (the reference builds both from one wave_func)
+// take the exact per-sample form.
+template <bool ENV, bool FILT, int MODE, bool GATED = false, bool FM = false>
 __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, int count,
                                                        int block_base,      // first block, relative to this call
                                                        uint32_t clock_base,  // absolute number of block_base (events)
@@ -303,6 +309,16 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     const int first_wave = __builtin_amdgcn_readfirstlane(wave_id);
     const int uniform_wave = __all(wave_id == first_wave) ? first_wave : -1;
     double phase = bk.phase[v];
+    static_assert(!(FM && GATED), "gated FM chains run in voice_mod_kernel");
+    double mod_freq = 0., mod_scale = 0., mod_phase = 0.;
+    int mod_wave = 0;
+    bool fm_paired = false;  // wave-uniform: carrier and modulator share a plain wave function
+    if (FM) {
+        mod_freq = bk.mod_par[v], mod_scale = bk.mod_par[(size_t)bk.n + v];
+        mod_wave = bk.mod_wave[v];
+        mod_phase = bk.mod_phase[v];
+        fm_paired = uniform_wave >= W_SINE && uniform_wave <= W_TRIANGLE && __all(mod_wave == wave_id);
+    }
 
     EnvParams ep;
     EnvState es;
@@ -444,8 +460,21 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
         const double omega = kTau * freq;  // oscillators.py:60  (TAU * frequency) * t
         const double start = phase;
         // wave-uniform: may this block use the fast remainder?
-        const bool fast_block =
+        bool fast_block =
             __all(omega >= 0. && start >= 0. && omega * c_time[kBlock] + start < 1e9);
+        const double mod_omega = kTau * mod_freq;
+        const double mod_start = mod_phase;
+        if (FM)  // ... and the modulator's, and |phase + intensity * modulator| < 1e9
+            fast_block = fast_block && fm_paired &&
+                         __all(mod_omega >= 0. && mod_start >= 0. &&
+                               mod_omega * c_time[kBlock] + mod_start < 1e9 && fabs(mod_scale) < 1e8);
+        // FmOscillator.sample, exactly, for one time point (oscillators.py:215-220)
+        auto fm_sample = [&](int w, double t) {
+            const double mp = np_mod_tau(mod_omega * t + mod_start);
+            const double m = wave_eval<false>(mod_wave, mp, kPi);
+            const double p = np_mod_tau(omega * t + start);
+            return wave_eval_any<false>(w, p + mod_scale * m, duty_edge);
+        };
 
         for (int c = 0; c < NCHUNK; ++c) {
             const int s0 = b * kBlock + c * CH;  // sample offset inside this launch
@@ -493,7 +522,39 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
 #pragma unroll
                         for (int j = 0; j < G; ++j) {
                             arg[j] = omega * tt.t[j] + start;  // oscillators.py:60
-                            if constexpr (FAST) {
+                            if constexpr (FM && FAST) {
+                                // modulator: Oscillator.sample of the same wave function
+                                const double marg = mod_omega * tt.t[j] + mod_start;
+                                const double mk = floor(marg * kInvTau);
+                                const double mp = __builtin_fma(-mk, kTau, marg);
+                                const double m = wave_eval<true>(wsel, mp, kPi);
+                                const double k = floor(arg[j] * kInvTau);
+                                const double ph = __builtin_fma(-k, kTau, arg[j]);
+                                // oscillators.py:220: wave(phase + intensity * modulator); the
+                                // remainder of that sum (sine, sawtooth) or of the sum + PI
+                                // (square, triangle: math.py:9-11) is x - floor(x/TAU) TAU for
+                                // either sign, as NumPy's fmod-then-sign-fix yields it
+                                const double q = ph + mod_scale * m;
+                                const double a = (wsel == W_SQUARE || wsel == W_TRIANGLE) ? q + kPi : q;
+                                const double qk = floor(a * kInvTau);
+                                const double r = __builtin_fma(-qk, kTau, a);
+                                hi_max = max(hi_max, max(max((uint32_t)__double2hiint(mp),
+                                                             (uint32_t)__double2hiint(ph)),
+                                                         (uint32_t)__double2hiint(r)));
+                                if (wsel == W_SINE) {
+                                    osc[j] = sin_wrapped(r);
+                                } else if (wsel == W_SQUARE) {
+                                    osc[j] = (r - kPi >= 0.) ? 1. : -1.;
+                                } else if (wsel == W_SAWTOOTH) {
+                                    osc[j] = div_pi(r) - 1.;
+                                } else {
+                                    double t4 = div_tau(4. * (r - kPi));
+                                    t4 = t4 < 0. ? t4 + 4. : t4;
+                                    osc[j] = 1. - fabs(t4 - 2.);
+                                }
+                            } else if constexpr (FM) {
+                                osc[j] = fm_sample(wsel, tt.t[j]);
+                            } else if constexpr (FAST) {
                                 const double k = floor(arg[j] * kInvTau);
                                 const double ph = __builtin_fma(-k, kTau, arg[j]);
                                 hi_max = max(hi_max, (uint32_t)__double2hiint(ph));
@@ -536,7 +597,9 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
 #pragma unroll
                         for (int j = 0; j < G; ++j) {
                             double x = osc[j];
-                            if constexpr (FAST) {
+                            if constexpr (FM && FAST) {
+                                x = fm_sample(wsel, tt.t[j]);
+                            } else if constexpr (FAST) {
                                 if (has_phase)
                                     x = wave_eval<true>(wsel, fmod_tau_fast(arg[j]), duty_edge);
                             }
@@ -571,14 +634,20 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                     case W_SQUARE: run_chunk(integral_constant<int, W_SQUARE>{}, Fast{}, unit); break;
                     case W_SAWTOOTH: run_chunk(integral_constant<int, W_SAWTOOTH>{}, Fast{}, unit); break;
                     case W_TRIANGLE: run_chunk(integral_constant<int, W_TRIANGLE>{}, Fast{}, unit); break;
-                    case W_PWM: run_chunk(integral_constant<int, W_PWM>{}, Fast{}, unit); break;
-                    default: run_chunk(integral_constant<int, -1>{}, Fast{}, unit); break;
+                    default:   // (FM: fast_block implies one of the four above)
+                        if constexpr (!FM) {
+                            if (uniform_wave == W_PWM)
+                                run_chunk(integral_constant<int, W_PWM>{}, Fast{}, unit);
+                            else
+                                run_chunk(integral_constant<int, -1>{}, Fast{}, unit);
+                        }
+                        break;
                     }
                 } else {
                     run_chunk(integral_constant<int, -1>{}, std::false_type{}, unit);
                 }
             };
-            if constexpr (MODE == OUT_MIX_MONO) {
+            if constexpr (MODE == OUT_MIX_MONO && !FM) {
                 if (unit_gain)
                     dispatch(std::true_type{});
                 else
@@ -591,6 +660,8 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
         // oscillators.py:66-67: next start phase is sample 256 of this block
         if (wave_id != W_EXTERNAL && wave_id != W_ONE)
             phase = np_mod_tau(omega * c_time[kBlock] + start);
+        if (FM)
+            mod_phase = np_mod_tau(mod_omega * c_time[kBlock] + mod_start);
         if (GATED && !run)
             phase = start;
     }
@@ -598,6 +669,8 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     // ---- store state ----------------------------------------------------------------
     if (live) {
         bk.phase[v] = phase;
+        if (FM)
+            bk.mod_phase[v] = mod_phase;
         bk.frequency_rw[v] = freq;
         bk.amplitude_rw[v] = amp;
         if (ENV) {

@@ -277,6 +277,8 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         e = upload_time_table_voice(t);
     if (e == hipSuccess)
         e = upload_time_table_mod(t);
+    if (e == hipSuccess)
+        e = upload_time_table_fm(t);
     if (e == hipSuccess) {
         void *p = nullptr;  // this device's copy of the scratch array (the device is current)
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
@@ -1480,6 +1482,12 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
     if (pipe >= 0)
         return launch_pipe_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                   n_blocks, span_total, pipe, partial, out);
+    // FmOscillator voices in a plain [Filter] chain: the fast kernel's FM form
+    const char *fm_knob = getenv("KLMI_FM_KERNEL");   // tuning knob: 0 = the general kernel
+    if (view.mod_target == MT_FM && plain_chain && !view.gated && view.poly == 0 &&
+        !(fm_knob && fm_knob[0] == '0'))
+        return launch_fm_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
+                                n_blocks, span_total, partial, out);
     if (view.mod_target != MT_NONE || !plain_chain || (view.gated && !fast_gated))
         return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                  n_blocks, span_total, partial, out);

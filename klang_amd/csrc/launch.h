@@ -30,11 +30,16 @@ inline hipError_t allow_dynamic_lds(const void *kernel, size_t bytes, std::atomi
 // t[n] = DT * n into the unit's own constant table (kTimeSlots doubles)
 hipError_t upload_time_table_voice(const double *t);
 hipError_t upload_time_table_mod(const double *t);
+hipError_t upload_time_table_fm(const double *t);
 
 // grid = ceil(count / 256) workgroups; `mode` is an OutMode
 hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStream_t st,
                                const BankView &view, int first, int count, int block_base, uint32_t clock_base,
                                int n_blocks, int span_total, float *partial, void *out);
+// voice_kernel<..., FM = true> (fm_tu.hip): FmOscillator voices, ungated, plain [Filter] chain
+hipError_t launch_fm_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
+                            int first, int count, int block_base, uint32_t clock_base,
+                            int n_blocks, int span_total, float *partial, void *out);
 hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                              int first, int count, int block_base, uint32_t clock_base,
                              int n_blocks, int span_total, float *partial, void *out);

@@ -104,14 +104,20 @@ def test_duty_cycle_modulated_by_audio_rate_lfo_vs_reference(hip, ctx, golden, w
         np.testing.assert_array_equal(got, want)
 
 
-def _modulated_banks(hip, ctx, oracle, n, nb, target, cutoff_lfo, seed, sine=False):
+def _modulated_banks(hip, ctx, oracle, n, nb, target, cutoff_lfo, seed, sine=False, paired=False,
+                     has_filter=True):
     """A config-3 style patch (saw -> ADSR -> biquad -> Mixer, notes on/off) with random
-    modulators; returns (hip bank, oracle bank, patch)."""
+    modulators; returns (hip bank, oracle bank, patch).  paired (FM): carrier and modulator of
+    a voice share their wave function, as FmOscillator builds them (oscillators.py:211-213),
+    64 consecutive voices share it too, and intensities take either sign."""
     rng = np.random.default_rng(seed)
     patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=max(1, nb // 2))
+    patch['has_filter'] = has_filter
     waves = rng.integers(0 if sine else 1, 4, n)
     if target == hip.MOD_DUTY:
         patch['wave'] = np.full(n, P.WAVE_PWM)
+    elif target == hip.MOD_FM and paired:
+        patch['wave'] = np.repeat(np.arange(-(-n // 64)) % 3 + 1, 64)[:n].astype(np.int32)
     elif target == hip.MOD_FM:
         patch['wave'] = rng.integers(0 if sine else 1, 4, n)
     table, grid = library_table(hip)
@@ -135,6 +141,8 @@ def _modulated_banks(hip, ctx, oracle, n, nb, target, cutoff_lfo, seed, sine=Fal
             ms, mo = .4 * rng.random(n), np.full(n, .5)
         mp = 6. * rng.random(n)
         mw = rng.integers(0 if sine else 1, 4, n)
+        if paired:
+            mw, ms = np.asarray(patch['wave']).copy(), 8. * rng.random(n) - 4.
         ob.mod_target = target
         ob.mod_frequency, ob.mod_scale, ob.mod_offset, ob.mod_phase = mf, ms, mo, mp.copy()
         ob.mod_wave = mw.astype(np.int32)
@@ -162,6 +170,34 @@ def test_modulated_chains_vs_oracle_bit_exact(hip, ctx, oracle, target, cutoff_l
         np.testing.assert_array_equal(hb.get_state(hip.F_LFO_PHASE), ob.lfo_phase)
     if target:
         np.testing.assert_array_equal(hb.get_state(hip.F_MOD_PHASE), ob.mod_phase)
+
+
+@pytest.mark.parametrize('has_filter,kernel', [(True, 'fast'), (False, 'fast'), (True, 'general')])
+def test_fm_voices_in_the_fast_kernel_vs_oracle_bit_exact(hip, ctx, oracle, monkeypatch, has_filter,
+                                                          kernel):
+    """FmOscillator voices whose wavefronts agree on the wave function run the fast kernel's
+    speculative FM region (three remainders under one check); voice streams, phases and filter
+    state equal the oracle's bit for bit, over split launches.  The last 64 voices have a
+    negative modulator frequency: their wavefront takes the exact per-sample form.  'general':
+    the same bank through voice_mod_kernel's FM branch (which gated, polyphonic and effect
+    chains with an FmOscillator still take)."""
+    if kernel == 'general':
+        monkeypatch.setenv('KLMI_FM_KERNEL', '0')
+    n, nb = 64 * 11, 14
+    hb, ob, patch = _modulated_banks(hip, ctx, oracle, n, nb, hip.MOD_FM, False, seed=23, paired=True,
+                                     has_filter=has_filter)
+    mf = ob.mod_frequency.copy()
+    mf[-64:] = -mf[-64:]
+    ob.mod_frequency = mf
+    hb.set(hip.F_MOD_FREQUENCY, mf)
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+    np.testing.assert_array_equal(hb.render_voices(nb, f64=True), want_voices)
+    mix = np.concatenate([hb.render(6), hb.render(8)])
+    assert np.abs(mix[:, 0, :] - want_mix[:, 0, :]).max() <= 1e-6
+    np.testing.assert_array_equal(hb.get_state(hip.F_PHASE), ob.phase)
+    np.testing.assert_array_equal(hb.get_state(hip.F_MOD_PHASE), ob.mod_phase)
+    if has_filter:
+        np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
 
 
 def test_modulated_chains_with_sines_within_tolerance(hip, ctx, oracle):
