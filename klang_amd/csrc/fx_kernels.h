@@ -1,0 +1,452 @@
+// fx_kernels.h -- the voice kernel for chains with a short, common effect program behind the
+// [Filter]: Tremolo, Delay and Gain stages (klang/audio/effects.py:58-70, 100-174), the program
+// known at compile time (gfx950).
+//
+// voice_mod_kernel (mod_kernels.h) interprets ANY stage program, stage-major over an LDS strip:
+// every stage is a loop of its own, so a stage that is one serial recurrence (the biquad, the
+// Tremolo's smoothing filter) runs at the latency of its dependent float64 operations with
+// nothing to fill the gaps -- one wavefront per SIMD is all a 65,536-voice bank gives the
+// scheduler.  Here the program is a template parameter and eight samples of the whole chain
+// are two regions of straight-line code, as in voice_kernel:
+//   1. the oscillator: eight independent samples, the wave function chosen by one scalar
+//      jump per group (closed-form phase, so its speculative remainder is repaired in place);
+//   2. envelope, biquad and the Tremolo's Lfo + smoothing filter -- three independent serial
+//      recurrences the scheduler interleaves -- with the Delay's eight delayed samples
+//      fetched before region 1 (the line is at least one buffer long, so they never depend on
+//      this group's writes) and the stages applied in patch order at the end.
+// Only the envelope is speculated with a redo (its stage switches depend on rounded values);
+// the Tremolo's remainder has its own check and exact form.  Per sample the arithmetic is the
+// reference's, operation for operation, and equal to voice_mod_kernel's bit for bit.
+#pragma once
+#include "bank_kernels.h"
+#include <type_traits>
+
+namespace klmi {
+
+// A program: up to three stage kinds (FxKind), four bits each, the first stage lowest.
+constexpr uint32_t fx_program(int a, int b = 0, int c = 0)
+{
+    return (uint32_t)a | ((uint32_t)b << 4) | ((uint32_t)c << 8);
+}
+constexpr int fx_program_kind(uint32_t prog, int s) { return (int)((prog >> (4 * s)) & 15u); }
+constexpr int fx_program_length(uint32_t prog)
+{
+    return fx_program_kind(prog, 2) ? 3 : fx_program_kind(prog, 1) ? 2 : fx_program_kind(prog, 0) ? 1 : 0;
+}
+constexpr int fx_program_find(uint32_t prog, int kind)   // stage index of `kind`, -1: none
+{
+    for (int s = 0; s < 3; ++s)
+        if (fx_program_kind(prog, s) == kind)
+            return s;
+    return -1;
+}
+
+struct __attribute__((packed, aligned(8))) DoublePair {
+    double a, b;
+};
+
+// grid.x = ceil(count / 256) workgroups of 4 waves; partial / out as voice_kernel.
+// The chain is bk.fx_kind = [FX_FILTER if FILT] + PROG's stages (the launcher checks).
+template <bool ENV, bool FILT, int MODE, uint32_t PROG>
+__global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first, int count,
+                                                          int block_base, uint32_t clock_base,
+                                                          int n_blocks, int span_total,
+                                                          float *__restrict__ partial,
+                                                          void *__restrict__ out)
+{
+    using TT = TileTraits<MODE>;
+    using T = typename TT::T;
+    constexpr int CH = TT::chunk;
+    constexpr int NCHUNK = kBlock / CH;
+    constexpr int PLANES = TT::planes;
+    constexpr bool MIX = (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
+    constexpr int G = 8;
+    constexpr int NSTAGE = fx_program_length(PROG);
+    constexpr int FIRST_STAGE = FILT ? 1 : 0;   // the Filter, when there is one, is stage 0
+    constexpr int TREM = fx_program_find(PROG, FX_TREMOLO);
+    constexpr int DELAY = fx_program_find(PROG, FX_DELAY);
+    static_assert(NSTAGE >= 1, "plain chains run in voice_kernel");
+
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    T *tile = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (PLANES ? PLANES : 1) * CH * TT::stride;
+
+    const int local = blockIdx.x * kGroup + threadIdx.x;
+    const bool live = local < count;
+    const int v = first + (live ? local : 0);
+    const size_t n = (size_t)bk.n;
+
+    // ---- parameters and state --------------------------------------------------------
+    double freq = bk.frequency_rw[v];
+    double amp = bk.amplitude_rw[v];
+    const int wave_id = bk.wave[v];
+    const double duty_edge = kTau * bk.duty[v];  // oscillators.py:259
+    const int first_wave = __builtin_amdgcn_readfirstlane(wave_id);
+    const int uniform_wave = __all(wave_id == first_wave) ? first_wave : -1;
+    double phase = bk.phase[v];
+
+    EnvParams ep{};
+    EnvState es{};
+    if (ENV) {
+        ep.aCoef = bk.env_coef[0 * n + v];
+        ep.aBase = bk.env_coef[1 * n + v];
+        ep.dCoef = bk.env_coef[2 * n + v];
+        ep.dBase = bk.env_coef[3 * n + v];
+        ep.rCoef = bk.env_coef[4 * n + v];
+        ep.rBase = bk.env_coef[5 * n + v];
+        ep.sustain = bk.env_coef[6 * n + v];
+        const uint32_t fl = bk.env_flags[v];
+        ep.loop = fl & 1u;
+        ep.retrigger = fl & 2u;
+        const uint32_t st = bk.env_state[v];
+        es.stage = (int)(st & 7u);
+        es.enabled = (st >> 8) & 1u;
+        es.value = bk.env_value[v];
+        es.select(ep);
+    }
+
+    Biquad bq{};
+    int coef_row = 0;
+    if (FILT) {
+        coef_row = bk.coef_index_rw[v];
+        const double *c = bk.coef_table + 5 * (size_t)coef_row;
+        bq.b0 = c[0], bq.b1 = c[1], bq.b2 = c[2], bq.a1 = c[3], bq.a2 = c[4];
+        bq.z0 = bk.z0[v];
+        bq.z1 = bk.z1[v];
+    }
+    const bool cutoff_lfo = FILT && bk.lfo_par != nullptr;  // uniform over the launch
+    double lfo_ph = cutoff_lfo ? bk.lfo_phase[v] : 0.;
+
+    // Tremolo (effects.py:100-133): rate, depth, duty cycle, one-pole smoothing filter
+    double trem_rate = 0., trem_depth = 0., trem_edge = 0., trem_b0 = 0., trem_a1 = 0.;
+    double trem_phase = 0., trem_z = 0.;
+    if constexpr (TREM >= 0) {
+        const double *par = bk.fx_par + (size_t)((FIRST_STAGE + TREM) * kFxSlots) * n + v;
+        trem_rate = par[0], trem_depth = par[n], trem_edge = kTau * par[2 * n];
+        trem_b0 = par[3 * n], trem_a1 = par[4 * n];
+        trem_phase = bk.fx_state[(size_t)(2 * (FIRST_STAGE + TREM)) * n + v];
+        trem_z = bk.fx_state[(size_t)(2 * (FIRST_STAGE + TREM) + 1) * n + v];
+    }
+    const double trem_floor = 1. - trem_depth;
+    // Delay (effects.py:136-174): the voice's own line, slots [len, len + 8) mirror [0, 8)
+    int delay_pos = 0, delay_len = 1;
+    double delay_fb = 0., delay_dw = 0.;
+    double *delay_line = nullptr;
+    if constexpr (DELAY >= 0) {
+        const double *par = bk.fx_par + (size_t)((FIRST_STAGE + DELAY) * kFxSlots) * n + v;
+        delay_pos = (int)bk.fx_state[(size_t)(2 * (FIRST_STAGE + DELAY)) * n + v];
+        delay_len = (int)par[0];
+        delay_fb = par[n], delay_dw = par[2 * n];
+        delay_line = bk.fx_ring + (size_t)v * bk.fx_ring_stride;
+    }
+    const double delay_dry = 1. - delay_dw;
+    // Gain stages (effects.py:58-70): one parameter each
+    double gain_par[NSTAGE];
+#pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+        gain_par[s] = fx_program_kind(PROG, s) == FX_GAIN
+                          ? bk.fx_par[(size_t)((FIRST_STAGE + s) * kFxSlots) * n + v]
+                          : 0.;
+
+    double gl = 0., gr = 0.;
+    if (MIX) {
+        gl = live ? bk.gain_l[v] : 0.;
+        if (MODE == OUT_MIX_STEREO)
+            gr = live ? bk.gain_r[v] : 0.;
+    }
+
+    uint32_t ev_i = bk.ev_offset[v] + bk.ev_cursor[v];
+    const uint32_t ev_end = bk.ev_offset[v + 1];
+    uint32_t next_ev = (live && ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
+
+    for (int b = 0; b < n_blocks; ++b) {
+        const uint32_t abs_block = clock_base + (uint32_t)b;
+        while (next_ev <= abs_block) {  // voices.py:55-64: notes at the block boundary
+            const uint32_t kind = bk.ev_kind[ev_i];
+            if (kind == 1u) {
+                if (ENV)
+                    es.gate(ep, true);
+                amp = bk.ev_velocity[ev_i];
+                freq = bk.ev_frequency[ev_i];
+            } else if (kind == 0u) {
+                if (ENV)
+                    es.gate(ep, false);
+            } else if (kind == 2u) {
+                if (FILT) {
+                    coef_row = bk.ev_index[ev_i];
+                    const double *c = bk.coef_table + 5 * (size_t)coef_row;
+                    bq.b0 = c[0], bq.b1 = c[1], bq.b2 = c[2], bq.a1 = c[3], bq.a2 = c[4];
+                }
+            } else {
+                freq = bk.ev_frequency[ev_i];
+            }
+            ++ev_i;
+            next_ev = (ev_i < ev_end) ? bk.ev_block[ev_i] : 0xFFFFFFFFu;
+        }
+        if (cutoff_lfo)
+            lfo_cutoff_step(bk, v, lfo_ph, coef_row, bq);
+
+        const double omega = kTau * freq;  // oscillators.py:60  (TAU * frequency) * t
+        const double start = phase;
+        const double t_end = c_time[kBlock];
+        // wave-uniform: every phase argument of this block is >= 0 and < 1e9 (fast remainder)
+        const bool fast_osc = uniform_wave >= W_SINE && uniform_wave <= W_PWM &&
+                              __all(omega >= 0. && start >= 0. && omega * t_end + start < 1e9);
+        const double trem_omega = kTau * trem_rate;   // effects.py:117-133: kTau * rate * t + start
+        const double trem_start = trem_phase;
+        const bool fast_trem =
+            TREM >= 0 && __all(trem_omega >= 0. && trem_start >= 0. && trem_omega * t_end + trem_start < 1e9);
+
+        // ---- region 1: eight oscillator samples ------------------------------------------
+        auto osc_group = [&](const Time8 &tt, int sample0, double (&osc)[G]) {
+            if (uniform_wave == W_ONE) {
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    osc[j] = 1.;
+                return;
+            }
+            if (uniform_wave == W_EXTERNAL) {
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    osc[j] = bk.ext_input[(size_t)(block_base * kBlock + sample0 + j) * n + v];
+                return;
+            }
+            double arg[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                arg[j] = omega * tt.t[j] + start;  // oscillators.py:60
+            if (fast_osc) {
+                double ph[G];
+                uint32_t hi_max = 0;
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const double k = floor(arg[j] * kInvTau);
+                    ph[j] = __builtin_fma(-k, kTau, arg[j]);
+                    hi_max = max(hi_max, (uint32_t)__double2hiint(ph[j]));
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) != 0, 0)) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        ph[j] = fmod_tau_fast(arg[j]);
+                }
+                switch (uniform_wave) {
+                case W_SINE:
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        osc[j] = wave_eval<true>(W_SINE, ph[j], duty_edge);
+                    break;
+                case W_SQUARE:
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        osc[j] = wave_eval<true>(W_SQUARE, ph[j], duty_edge);
+                    break;
+                case W_SAWTOOTH:
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        osc[j] = wave_eval<true>(W_SAWTOOTH, ph[j], duty_edge);
+                    break;
+                case W_TRIANGLE:
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        osc[j] = wave_eval<true>(W_TRIANGLE, ph[j], duty_edge);
+                    break;
+                default:
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        osc[j] = wave_eval<true>(W_PWM, ph[j], duty_edge);
+                    break;
+                }
+            } else {
+                // mixed wavefronts, negative or huge phases: the exact form, lane by lane
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    if (wave_id == W_ONE)
+                        osc[j] = 1.;
+                    else if (wave_id == W_EXTERNAL)
+                        osc[j] = bk.ext_input[(size_t)(block_base * kBlock + sample0 + j) * n + v];
+                    else
+                        osc[j] = wave_eval<false>(wave_id, np_mod_tau(arg[j]), duty_edge);
+                }
+            }
+        };
+
+        for (int c = 0; c < NCHUNK; ++c) {
+            const int s0 = b * kBlock + c * CH;  // sample offset inside this launch
+            const Time8 *times = reinterpret_cast<const Time8 *>(c_time) + ((c * CH) >> 3);
+            for (int i8 = 0; i8 < CH; i8 += G) {
+                const Time8 tt = times[i8 >> 3];
+                // the Delay's eight delayed samples, asked for first
+                double old[G] = {};
+                int idx0 = 0;
+                if constexpr (DELAY >= 0) {
+                    idx0 = delay_pos + c * CH + i8;
+                    idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
+                    const DoublePair *line = reinterpret_cast<const DoublePair *>(delay_line + idx0);
+#pragma unroll
+                    for (int j = 0; j < G; j += 2) {
+                        const DoublePair o = line[j >> 1];
+                        old[j] = o.a, old[j + 1] = o.b;
+                    }
+                }
+
+                double osc[G];
+                osc_group(tt, s0 + i8, osc);
+
+                // ---- region 2: the serial recurrences, side by side ------------------------
+                double y[G];
+                unsigned long long redo = 0;
+                double vv = 0.;
+                if (ENV) {
+                    // v -> fl(base + fl(v*coef)) is monotone in v: if any of the 8 values
+                    // crossed the stage's limit, the last one did (see voice_kernel)
+                    vv = es.value;
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        vv = es.base + vv * es.coef;           // _envelope.c:579-624
+                        y[j] = amp * osc[j] * vv;              // voices.py:73 (amplitude*osc)*env
+                    }
+                    redo = __builtin_amdgcn_ballot_w64(es.reached(vv));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        y[j] = osc[j];
+                }
+                Biquad sp = bq;
+                if (FILT) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        y[j] = sp.step(y[j]);
+                }
+                // the Tremolo's gain for these samples does not depend on the signal:
+                // Lfo (PWM wave) -> one-pole lfilter([b0], [1, a1]) -> depth blend
+                double tg[G];
+                double tz = trem_z;
+                bool trem_exact = false;
+                if constexpr (TREM >= 0) {
+                    uint32_t hi_max = 0;
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        const double pa = trem_omega * tt.t[j] + trem_start;
+                        const double k = floor(pa * kInvTau);
+                        const double tp = __builtin_fma(-k, kTau, pa);
+                        hi_max = max(hi_max, (uint32_t)__double2hiint(tp));
+                        const double pwm = (tp < trem_edge) ? 1. : -1.;
+                        const double yt = tz + trem_b0 * pwm;
+                        tz = 0. * pwm - trem_a1 * yt;
+                        tg[j] = trem_floor + trem_depth * (.5 + .5 * yt);
+                    }
+                    trem_exact = !fast_trem || __builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) != 0;
+                }
+
+                if (__builtin_expect(redo != 0, 0)) {
+                    // some lane's envelope switches stage in these 8 samples: the exact state
+                    // machine, from the uncommitted state
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        double x = amp * osc[j] * es.step(ep);
+                        if (FILT)
+                            x = bq.step(x);
+                        y[j] = x;
+                    }
+                } else {
+                    if (ENV)
+                        es.value = vv;
+                    if (FILT)
+                        bq.z0 = sp.z0, bq.z1 = sp.z1;
+                }
+                if constexpr (TREM >= 0) {
+                    if (__builtin_expect(trem_exact, 0)) {
+                        tz = trem_z;
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const double tp = np_mod_tau(trem_omega * tt.t[j] + trem_start);
+                            const double pwm = (tp < trem_edge) ? 1. : -1.;
+                            const double yt = tz + trem_b0 * pwm;
+                            tz = 0. * pwm - trem_a1 * yt;
+                            tg[j] = trem_floor + trem_depth * (.5 + .5 * yt);
+                        }
+                    }
+                    trem_z = tz;
+                }
+
+                // ---- the stages, in patch order ---------------------------------------------
+#pragma unroll
+                for (int s = 0; s < NSTAGE; ++s) {
+                    const int kind = fx_program_kind(PROG, s);   // folds: PROG and s are constants
+                    if (kind == FX_TREMOLO) {
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            y[j] = tg[j] * y[j];
+                    } else if (kind == FX_GAIN) {      // effects.py:67-70
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            y[j] = gain_par[s] * y[j];
+                    } else if (kind == FX_DELAY) {     // effects.py:166-174: wet = new + feedback * delayed
+                        double w[G];
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            w[j] = y[j] + delay_fb * old[j];
+                        if (live) {
+                            DoublePair *line = reinterpret_cast<DoublePair *>(delay_line + idx0);
+#pragma unroll
+                            for (int j = 0; j < G; j += 2)
+                                line[j >> 1] = DoublePair{w[j], w[j + 1]};
+                            // keep slots and mirror in step where the 8 touch either end
+                            if (idx0 < 8 || idx0 + G > delay_len) {
+#pragma unroll
+                                for (int j = 0; j < G; ++j) {
+                                    const int idx = idx0 + j;
+                                    if (idx >= delay_len)
+                                        delay_line[idx - delay_len] = w[j];
+                                    else if (idx < 8)
+                                        delay_line[idx + delay_len] = w[j];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            y[j] = delay_dry * y[j] + delay_dw * w[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                    emit_sample<MODE>(tile, i8 + j, lane, y[j], gl, gr, live, out, s0, count, local);
+            }
+            flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
+        }
+        // next start phases: sample 256 of this block (oscillators.py:66-67)
+        if (wave_id != W_EXTERNAL && wave_id != W_ONE)
+            phase = np_mod_tau(omega * t_end + start);
+        if constexpr (TREM >= 0)
+            trem_phase = np_mod_tau(trem_omega * t_end + trem_start);
+        if constexpr (DELAY >= 0)
+            delay_pos = (delay_pos + kBlock) % delay_len;
+    }
+
+    if (live) {
+        bk.phase[v] = phase;
+        bk.frequency_rw[v] = freq;
+        bk.amplitude_rw[v] = amp;
+        if (ENV) {
+            bk.env_value[v] = es.value;
+            bk.env_state[v] = (uint32_t)es.stage | (es.enabled ? 0x100u : 0u);
+        }
+        if (FILT) {
+            bk.z0[v] = bq.z0;
+            bk.z1[v] = bq.z1;
+            bk.coef_index_rw[v] = coef_row;
+            if (cutoff_lfo)
+                bk.lfo_phase[v] = lfo_ph;
+        }
+        if constexpr (TREM >= 0) {
+            bk.fx_state[(size_t)(2 * (FIRST_STAGE + TREM)) * n + v] = trem_phase;
+            bk.fx_state[(size_t)(2 * (FIRST_STAGE + TREM) + 1) * n + v] = trem_z;
+        }
+        if constexpr (DELAY >= 0)
+            bk.fx_state[(size_t)(2 * (FIRST_STAGE + DELAY)) * n + v] = (double)delay_pos;
+        bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
+    }
+}
+
+}  // namespace klmi

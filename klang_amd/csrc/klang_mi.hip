@@ -279,6 +279,8 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         e = upload_time_table_mod(t);
     if (e == hipSuccess)
         e = upload_time_table_fm(t);
+    if (e == hipSuccess)
+        e = upload_time_table_fx(t);
     if (e == hipSuccess) {
         void *p = nullptr;  // this device's copy of the scratch array (the device is current)
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
@@ -1488,6 +1490,12 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
         !(fm_knob && fm_knob[0] == '0'))
         return launch_fm_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                 n_blocks, span_total, partial, out);
+    // a short Tremolo / Delay / Gain program behind the [Filter]: compiled in
+    const char *fx_knob = getenv("KLMI_FX_KERNEL");   // tuning knob: 0 = the general kernel
+    const uint32_t program = fx_knob && fx_knob[0] == '0' ? 0 : fx_program_of(view, filt, MODE);
+    if (program != 0)
+        return launch_fx_kernel(program, env, filt, MODE, st, view, first, count, block_base,
+                                clock_base, n_blocks, span_total, partial, out);
     if (view.mod_target != MT_NONE || !plain_chain || (view.gated && !fast_gated))
         return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                  n_blocks, span_total, partial, out);

@@ -31,6 +31,7 @@ inline hipError_t allow_dynamic_lds(const void *kernel, size_t bytes, std::atomi
 hipError_t upload_time_table_voice(const double *t);
 hipError_t upload_time_table_mod(const double *t);
 hipError_t upload_time_table_fm(const double *t);
+hipError_t upload_time_table_fx(const double *t);
 
 // grid = ceil(count / 256) workgroups; `mode` is an OutMode
 hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStream_t st,
@@ -40,6 +41,13 @@ hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStr
 hipError_t launch_fm_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                             int first, int count, int block_base, uint32_t clock_base,
                             int n_blocks, int span_total, float *partial, void *out);
+// voice_fx_kernel (fx_tu.hip): the compiled-in effect program a bank's stage list matches
+// (0: none -- the general kernel interprets it), and its launcher
+uint32_t fx_program_of(const BankView &view, bool filt, int mode);
+hipError_t launch_fx_kernel(uint32_t prog, bool env, bool filt, int mode, hipStream_t st,
+                            const BankView &view, int first, int count, int block_base,
+                            uint32_t clock_base, int n_blocks, int span_total, float *partial,
+                            void *out);
 hipError_t launch_mod_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                              int first, int count, int block_base, uint32_t clock_base,
                              int n_blocks, int span_total, float *partial, void *out);

@@ -118,6 +118,86 @@ def test_effect_chains_vs_oracle_many_voices(hip, ctx, oracle):
     np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
 
 
+PROGRAMS = ['T', 'D', 'G', 'TG', 'DG', 'TD', 'DT']
+
+
+@pytest.mark.parametrize('program,has_filter,kernel',
+                         [(p, f, 'compiled') for p in PROGRAMS for f in (True, False)]
+                         + [('TD', True, 'general'), ('DG', False, 'general')])
+def test_compiled_effect_programs_vs_oracle_bit_exact(hip, ctx, oracle, monkeypatch, program,
+                                                      has_filter, kernel):
+    """The Tremolo / Delay / Gain programs voice_fx_kernel is compiled for (fx_tu.hip), behind
+    the Filter or without one: 64 * 9 + 20 voices with notes, per-voice stage parameters, wave
+    functions that differ from wavefront to wavefront (one wavefront mixed), some negative
+    Tremolo rates (the exact remainder) -- float64 streams, stage state and delay lines
+    positions equal the oracle's bit for bit, the mix over split launches within 1e-6.
+    'general': the same through voice_mod_kernel's stage interpreter."""
+    if kernel == 'general':
+        monkeypatch.setenv('KLMI_FX_KERNEL', '0')
+    n, nb = 64 * 9 + 20, 12
+    rng = np.random.default_rng(40 + len(program) + 7 * PROGRAMS.index(program))
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=6)
+    patch['has_filter'] = has_filter
+    waves = np.repeat(np.arange(-(-n // 64)) % 3 + 1, 64)[:n]     # square, saw, triangle
+    waves[128:192] = rng.integers(1, 4, 64)                         # a mixed wavefront
+    patch['wave'] = waves.astype(np.int32)
+    rate = 1. + 9. * rng.random(n)
+    rate[300:310] = -rate[300:310]
+    make = {'T': lambda: (hip.FX_TREMOLO, rate, rng.random(n), rng.random(n), .1 + .8 * rng.random(n)),
+            'D': lambda: (hip.FX_DELAY, .006 + .05 * rng.random(n), .9 * rng.random(n), rng.random(n)),
+            'G': lambda: (hip.FX_GAIN, 1.5 * rng.random(n))}
+    stages = ([(hip.FX_FILTER,)] if has_filter else []) + [make[k]() for k in program]
+    table, grid = library_table(hip)
+    from tests.helpers import oracle_bank_from_patch
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.set_effects(stages)
+    hb = hip.Bank(ctx, n, has_env=True, has_filter=has_filter, effects=[s[0] for s in stages])
+    hb.load_patch(patch)
+    for s, st in enumerate(stages):
+        for k, p in enumerate(st[1:]):
+            hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+    np.testing.assert_array_equal(hb.render_voices(nb, f64=True), want_voices)
+    mix = np.concatenate([hb.render(5), hb.render(7)])
+    assert np.abs(want_mix).max() > 1e-3
+    assert np.abs(mix[:, 0, :] - want_mix[:, 0, :]).max() <= 1e-6
+    for s, st in enumerate(stages):
+        if st[0] == hip.FX_TREMOLO:
+            np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(s, 0)), ob.fx_state[s, 0])
+            np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(s, 1)), ob.fx_state[s, 1])
+        if st[0] == hip.FX_DELAY:
+            np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(s, 0)), ob.fx_state[s, 0])
+    np.testing.assert_array_equal(hb.get_state(hip.F_PHASE), ob.phase)
+    if has_filter:
+        np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
+    hb.close()
+
+
+def test_compiled_effect_program_under_a_stereo_mixer(hip, ctx, oracle):
+    """Filter -> Tremolo -> Gain chains into a StereoMixer (the OUT_MIX_STEREO instantiation)."""
+    n, nb = 200, 8
+    rng = np.random.default_rng(77)
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=4)
+    patch['stereo'] = True
+    patch['pan'] = 2. * rng.random(n) - 1.
+    stages = [(hip.FX_FILTER,), (hip.FX_TREMOLO, 1. + 9. * rng.random(n), rng.random(n), rng.random(n),
+                                 .1 + .8 * rng.random(n)), (hip.FX_GAIN, rng.random(n))]
+    table, grid = library_table(hip)
+    from tests.helpers import oracle_bank_from_patch
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.set_effects(stages)
+    hb = hip.Bank(ctx, n, has_env=True, has_filter=True, stereo=True, effects=[s[0] for s in stages])
+    hb.load_patch(patch)
+    for s, st in enumerate(stages):
+        for k, p in enumerate(st[1:]):
+            hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    want_mix, _ = ob.render(nb, patch.events)
+    mix = np.concatenate([hb.render(3), hb.render(5)])
+    assert mix.shape == want_mix.shape == (nb, 2, B)
+    assert np.abs(mix - want_mix).max() <= 1e-6 and np.abs(want_mix).max() > 1e-3
+    hb.close()
+
+
 def test_crusher_and_ring_modulator_vs_oracle_many_voices(hip, ctx, oracle):
     """600 voices through Gain -> Bitcrusher -> RingModulator(non-sine Lfo) -> Subsampler ->
     Filter with per-voice parameters; Gain up to 1.5 so that the int16 wrap of the crusher
