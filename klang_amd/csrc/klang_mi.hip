@@ -1483,7 +1483,7 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
     const int pipe = pipe_voices_log2(view, filt, count, MODE, n_cus);
     if (pipe >= 0)
         return launch_pipe_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
-                                  n_blocks, span_total, pipe, partial, out);
+                                  n_blocks, span_total, pipe, n_cus, partial, out);
     // FmOscillator voices in a plain [Filter] chain: the fast kernel's FM form
     const char *fm_knob = getenv("KLMI_FM_KERNEL");   // tuning knob: 0 = the general kernel
     if (view.mod_target == MT_FM && plain_chain && !view.gated && view.poly == 0 &&

@@ -60,7 +60,7 @@ int pipe_voices_log2(const BankView &view, bool filt, int count, int mode, int n
 int voice_partial_rows(const BankView &view, bool filt, int count, int mode, int n_cus);
 hipError_t launch_pipe_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                               int first, int count, int block_base, uint32_t clock_base,
-                              int n_blocks, int span_total, int voices_log2, float *partial,
-                              void *out);
+                              int n_blocks, int span_total, int voices_log2, int n_cus,
+                              float *partial, void *out);
 
 }  // namespace klmi

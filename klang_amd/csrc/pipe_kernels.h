@@ -56,14 +56,17 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// grid.x = ceil(count / V) workgroups of 4 waves.
+// grid.x workgroups of 4 waves: the first n_big own V = 2^voices_log2 voices each, the others
+// half as many (pipe_groups in pipe_tu.hip: a grid that is a whole number of workgroups per
+// compute unit -- 20,480 voices on 256 CUs are 512 x 32 + 256 x 16, three workgroups and 80
+// voices on every CU instead of 640 x 32 with three on half of them).
 // partial: [gridDim.x][n_blocks*planes*256] float32 (mix modes)
 // out:     [count][span_total] per-voice rows (OUT_VOICES_F32 / OUT_VOICES_F64)
 template <bool ENV, bool FILT, int MODE>
 __global__ __launch_bounds__(kGroup) void voice_pipe_kernel(BankView bk, int first, int count,
                                                             int block_base, uint32_t clock_base,
                                                             int n_blocks, int span_total,
-                                                            int voices_log2,
+                                                            int voices_log2, int n_big,
                                                             float *__restrict__ partial,
                                                             void *__restrict__ out)
 {
@@ -73,19 +76,23 @@ __global__ __launch_bounds__(kGroup) void voice_pipe_kernel(BankView bk, int fir
     using T = typename TileTraits<MODE>::T;
 
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int V = 1 << voices_log2;
+    const bool big = (int)blockIdx.x < n_big;   // uniform over the workgroup
+    const int group_log2 = big ? voices_log2 : voices_log2 - 1;
+    const int V = 1 << group_log2;
     double *xbuf = reinterpret_cast<double *>(smem_raw);           // [2][V][pitch]
     double *ybuf = xbuf + 2 * kPipePitch * V;                      // [2][V][pitch]
     double *gains = ybuf + 2 * kPipePitch * V;                     // [2][V]: left (or mono), right
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int base_voice = blockIdx.x * V;   // first voice of the workgroup, relative to `first`
+    // first voice of the workgroup, relative to `first`
+    const int base_voice = big ? (int)blockIdx.x << voices_log2
+                               : (n_big << voices_log2) + (((int)blockIdx.x - n_big) << group_log2);
     const int rounds = n_blocks * kPipeRounds;
 
     // ---- set-up per role ------------------------------------------------------------------
     // oscillator lanes: q = 0..127, Lv lanes per voice, Ks samples per lane and round
     const int q = (int)threadIdx.x - 64;
-    const int Lv = V >= 4 ? 128 >> voices_log2 : 32;
+    const int Lv = V >= 4 ? 128 >> group_log2 : 32;
     const int Ks = kPipeRound / Lv;
     const int o_voice = q >= 0 ? q / Lv : 0, o_sub = q >= 0 ? q % Lv : 0;
     const bool o_role = wave == 1 || wave == 2;

@@ -327,6 +327,20 @@ def test_effect_patches_match_the_host_evaluation(hip, name):
     assert np.abs(got - want).max() <= 1e-5
 
 
+def test_block_rate_patched_parameters_vs_reference_fixture(hip, golden):
+    """The reference's own output for host Lfos patched into Tremolo.rate / depth and Gain.gain
+    (tests/golden/effects_patched.npz, tools/gen_golden.py) vs the device path: the Lfos stay
+    host blocks, the bank follows their values buffer by buffer."""
+    from tests.test_host_blocks import patched_parameter_patch
+    want = golden('effects_patched')['patched_parameters']
+    dur = len(want) * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(patched_parameter_patch() | Dac(), offline=True, duration=dur,
+                                   fadeout=0.))
+    assert got.shape == (want.size, 1) and np.abs(want).max() > .05
+    from tests.helpers import report
+    assert report('effect parameters patched at block rate', np.abs(got[:, 0] - want.ravel()).max()) <= 1e-5
+
+
 def test_host_side_gain_edits_reach_the_device(hip):
     from klang_amd.audio import Gain
     gain = Gain(1.)

@@ -417,6 +417,34 @@ def test_polyphonic_patch_4096_vs_oracle(hip, ctx, oracle):
     np.testing.assert_array_equal(bank.get_state(hip.F_Z1), ob.z1)
 
 
+@pytest.mark.parametrize('n,has_filter', [(5000, True), (20001, False)])
+def test_pipelined_kernel_with_two_group_sizes_vs_oracle(hip, ctx, oracle, n, has_filter):
+    """Bank sizes for which the pipelined kernel's grid is not a whole number of workgroups
+    per compute unit: it then runs workgroups of two sizes (pipe_tu.hip pipe_groups; on 256
+    CUs 5,000 voices are 482 x 8 + 286 x 4, 20,001 are 483 x 32 + 285 x 16 with a ragged
+    last one).  Voice streams from both kinds of workgroup, mix and state vs the oracle."""
+    nb = 10
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=5)
+    patch['has_filter'] = has_filter
+    table, grid = library_table(hip)
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True,
+                                      n_threads=min(8, oracle.max_threads()))
+    bank = hip_bank_from_patch(hip, ctx, patch)
+    mix = np.concatenate([bank.render(4), bank.render(6)])
+    assert np.abs(mix[:, 0, :] - want_mix[:, 0, :]).max() <= 1e-6
+    np.testing.assert_array_equal(bank.get_state(hip.F_PHASE), ob.phase)
+    stage, value, enabled = ob.env_state()
+    np.testing.assert_array_equal(bank.get_state(hip.F_ENV_VALUE), value)
+    np.testing.assert_array_equal(bank.get_state(hip.F_ENV_STAGE), stage)
+    if has_filter:
+        np.testing.assert_array_equal(bank.get_state(hip.F_Z0), ob.z0)
+    # per-voice rows are a launch over the whole bank too (preview from the initial state)
+    fresh = hip_bank_from_patch(hip, ctx, patch)
+    got = fresh.render_voices(nb, f64=True)
+    np.testing.assert_array_equal(got, want_voices)
+
+
 def test_full_size_config3_properties(hip, ctx, oracle):
     """BASELINE config 3 at its full 65,536 voices (few blocks): shard-sum
     invariance, launch-split invariance, linearity in the gains, and the mix

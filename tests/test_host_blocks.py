@@ -303,6 +303,60 @@ def test_effect_blocks_match_reference_fixtures(golden):
         Bitcrusher(16)
 
 
+def patched_parameter_patch():
+    """The patch of tests/golden/effects_patched.npz 'patched_parameters' (tools/gen_golden.py):
+    host Lfos at block rate into Tremolo.rate / depth and Gain.gain of three voice chains."""
+    from klang_amd.audio import (ADSR, Filter, Gain, Lfo, Mixer, Oscillator, Tremolo, Voice,
+                                 sawtooth, triangle)
+    from klang_amd.messages import Note
+    mixer = Mixer()
+    for k in range(3):
+        voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+        voice.input.push(Note(0, .8, frequency=98. * (k + 1)))
+        trem, gain = Tremolo(rate=4., depth=.5, smoothness=.4), Gain(.5)
+        Lfo(frequency=.7 + k, outputRange=(2., 9.)) | trem.rate
+        Lfo(frequency=1.3, wave_func=triangle, outputRange=(.2, .9)) | trem.depth
+        Lfo(frequency=2. + k, outputRange=(.1, 1.)) | gain.gain
+        mixer += voice | Filter(frequency=900.) | trem | gain
+    return mixer
+
+
+def test_block_rate_patched_effect_parameters_vs_reference_fixture(golden):
+    from klang_amd.schedule import determine_execution_order
+    want = golden('effects_patched')['patched_parameters']
+    mixer = patched_parameter_patch()
+    order = determine_execution_order([mixer])
+    outs = []
+    for _ in range(len(want)):
+        for blk in order:
+            blk.update()
+        outs.append(np.array(mixer.output.value, dtype=float))
+    # closed-form Butterworth row and one-pole design vs scipy's: a few 1e-14 relative
+    np.testing.assert_allclose(np.array(outs), want, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('length', [100, 200, 255, 17])
+def test_delay_lines_shorter_than_a_buffer_vs_reference_fixture(golden, length):
+    """int(time * 44100) < 256: RingBuffer.extend's tail and head copies land inside the
+    window Delay.update reads back (ring_buffer.py:88-109, effects.py:166-174); the host
+    mirror reproduces the reference's result.  (The device path refuses such a Delay: see
+    test_find_fusable_reports_what_it_cannot_fuse / DESIGN.md.)"""
+    from klang_amd.audio import Delay, Oscillator, sawtooth
+    from klang_amd.schedule import determine_execution_order
+    want = golden('effects_patched')['delay_short_%d' % length]
+    osc = Oscillator(frequency=220., wave_func=sawtooth)
+    dl = Delay(time=(length + .5) / 44100., feedback=.6, drywet=.4)
+    osc | dl
+    assert dl.ring.length == length
+    order = determine_execution_order([dl])
+    outs = []
+    for _ in range(len(want)):
+        for o in order:
+            o.update()
+        outs.append(np.array(dl.output.value, dtype=float))
+    np.testing.assert_array_equal(np.array(outs), want)
+
+
 # ---- synthesizers (synthesizer.py:87-219) ------------------------------------------
 def _notes(*pitches, velocity=1.):
     from klang_amd.messages import Note

@@ -556,6 +556,31 @@ def main():
     fx['stereo_delay_mono_in'] = stereo_delay_run(False)
     save('effects', **fx)
 
+    # ---- effect parameters driven at block rate, delay lines shorter than a buffer -------
+    # effects.py:58-70, 73-133: Gain.gain, Tremolo.rate / depth are value inputs; a host Lfo
+    # (shape 1, oscillators.py:143-190) patched into them moves them once per buffer.
+    fp = {}
+    mixer = Mixer()
+    voices = []
+    for k in range(3):
+        voice = A.Voice(OSC.Oscillator(wave_func=W.sawtooth), A.ADSR(.01, .05, .6, .04))
+        trem, gain = FX.Tremolo(rate=4., depth=.5, smoothness=.4), FX.Gain(.5)
+        OSC.Lfo(frequency=.7 + k, outputRange=(2., 9.)) | trem.rate
+        OSC.Lfo(frequency=1.3, wave_func=W.triangle, outputRange=(.2, .9)) | trem.depth
+        OSC.Lfo(frequency=2. + k, outputRange=(.1, 1.)) | gain.gain
+        mixer += voice | FX.Filter(frequency=900.) | trem | gain
+        voices.append(voice)
+    hooks = {0: [lambda v=v, k=k: v.input.push(Note(0, .8, frequency=98. * (k + 1)))
+                 for k, v in enumerate(voices)]}
+    fp['patched_parameters'] = run_graph(mixer, 24, hooks)
+    # Delay(time) with int(time * 44100) < 256: RingBuffer.extend's tail / head copies
+    # overlap the window that Delay.update reads back (ring_buffer.py:88-109, effects.py:166-174)
+    for length in (100, 200, 255, 17):
+        fp['delay_short_%d' % length], dl = fx_run(
+            lambda: FX.Delay(time=(length + .5) / 44100., feedback=.6, drywet=.4), n_blocks=12)
+        assert dl.ring.length == length
+    save('effects_patched', **fp)
+
     # ---- synthesizers: synthesizer.py:87-219 -----------------
     from klang.audio import synthesizer as SY
     syn = {}
