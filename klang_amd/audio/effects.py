@@ -27,6 +27,15 @@ __all__ = ['Gain', 'Transformer', 'TanhDistortion', 'OctaveDistortion', 'Tremolo
            'DelayLine', 'AudioSplitter', 'AudioCombiner', 'StereoDelay', 'Subsampler', 'Bitcrusher', 'RingModulator', 'low_pass_coefficients']
 
 
+def _value_ports(owner, *spec):
+    """inputs = [signal input] + one value port per (kind, initial value); -> the value ports."""
+    ports = [kind(owner=owner) for kind, _ in spec]
+    for port, (_, initial) in zip(ports, spec):
+        port.set_value(initial)
+    owner.inputs = [Input(owner=owner)] + ports
+    return ports
+
+
 @functools.lru_cache()
 def low_pass_coefficients(frequency):
     """Single-pole low-pass (b, a) (effects.py:33-55), from the library's helper."""
@@ -102,17 +111,13 @@ class Tremolo(Composite):
 
     def __init__(self, rate=3., depth=.8, smoothness=1., dutyCycle=.5):
         super().__init__(nOutputs=1)
-        self.inputs = [Input(owner=self), Relay(owner=self), Input(owner=self),
-                       Input(owner=self), Relay(owner=self)]
-        _, self.rate, self.depth, self.smoothness, self.dutyCycle = self.inputs
-        self.rate.set_value(rate)
-        self.depth.set_value(depth)
-        self.smoothness.set_value(smoothness)
-        self.dutyCycle.set_value(dutyCycle)
+        # rate and duty cycle are relays: they pass on to the pulse Lfo inside
+        self.rate, self.depth, self.smoothness, self.dutyCycle = _value_ports(
+            self, (Relay, rate), (Input, depth), (Input, smoothness), (Relay, dutyCycle))
         self.lfo = PwmOscillator(rate)
-        self.rate.connect(self.lfo.frequency)
-        self.dutyCycle.connect(self.lfo.dutyCycle)
-        self.zi = np.zeros(1)
+        for relay, target in ((self.rate, self.lfo.frequency), (self.dutyCycle, self.lfo.dutyCycle)):
+            relay.connect(target)
+        self.zi = np.zeros(1)      # state of the smoothing filter
 
     @staticmethod
     def smoothing_coefficients(smoothness, dutyCycle):
@@ -120,20 +125,18 @@ class Tremolo(Composite):
         return low_pass_coefficients(1. / decay)
 
     def update(self):
-        depth = self.depth.value
         (b0,), (_, a1) = self.smoothing_coefficients(self.smoothness.value, self.dutyCycle.value)
         self.lfo.update()
-        pwm = self.lfo.output.value
-        # scipy.signal.lfilter([b0], [1, a1], pwm, zi): direct form II transposed, order 1
+        pulse = self.lfo.output.value
+        # scipy.signal.lfilter([b0], [1, a1], pulse, zi): direct form II transposed, order 1
         smooth = np.empty(BUFFER_SIZE)
         z = float(self.zi[0])
-        for i in range(BUFFER_SIZE):
-            y = z + b0 * pwm[i]
-            z = 0. * pwm[i] - a1 * y
-            smooth[i] = y
+        for i, p in enumerate(pulse):
+            smooth[i] = y = z + b0 * p
+            z = 0. * p - a1 * y
         self.zi = np.array([z])
-        env = (1. - depth) + depth * (.5 + .5 * smooth)
-        self.output.set_value(env * self.input.value)
+        depth = self.depth.value
+        self.output.set_value(((1. - depth) + depth * (.5 + .5 * smooth)) * self.input.value)
 
 
 DelayLine = RingBuffer   # the Delay's line is the reference's RingBuffer (effects.py:158)
@@ -154,12 +157,12 @@ class Delay(Block):
         self.ring = DelayLine(int(self.time * SAMPLING_RATE), int(self.MAX_TIME * SAMPLING_RATE))
 
     def update(self):
-        new = self.input.get_value()
-        if np.ndim(new) != MONO:
-            new = new.sum(axis=0) / new.shape[0]
-        old = self.ring.peek()
-        self.ring.extend(new + self.feedback * old)
-        self.output.set_value(blend(new, old, self.drywet))
+        dry = self.input.get_value()
+        if np.ndim(dry) != MONO:
+            dry = dry.sum(axis=0) / dry.shape[0]
+        window = self.ring.peek()       # a view of the line: it shows what extend() writes next
+        self.ring.extend(dry + self.feedback * window)
+        self.output.set_value(blend(dry, window, self.drywet))
 
 
 class AudioSplitter(Block):
@@ -170,13 +173,10 @@ class AudioSplitter(Block):
         super().__init__(nInputs=1, nOutputs=nOutputs)
 
     def update(self):
-        samples = self.input.value
-        if np.ndim(samples) == MONO:
-            for output in self.outputs:
-                output.set_value(samples)
-        else:
-            for channel, output in zip(samples, self.outputs):
-                output.set_value(channel)
+        signal = self.input.value
+        rows = [signal] * len(self.outputs) if np.ndim(signal) == MONO else signal
+        for port, row in zip(self.outputs, rows):
+            port.set_value(row)
 
 
 class AudioCombiner(Block):
@@ -199,16 +199,14 @@ class StereoDelay(Composite):
 
     def __init__(self, leftTime=1., rightTime=1., leftFeedback=.1, rightFeedback=.1, drywet=.5):
         super().__init__()
-        self.inputs = [Relay(owner=self)]
-        self.outputs = [Relay(owner=self)]
-        splitter = AudioSplitter(nOutputs=STEREO)
+        self.inputs, self.outputs = [Relay(owner=self)], [Relay(owner=self)]
         self.leftDelay = Delay(leftTime, leftFeedback, drywet)
         self.rightDelay = Delay(rightTime, rightFeedback, drywet)
-        combiner = AudioCombiner(nInputs=STEREO)
-        self.input.connect(splitter.input)
-        splitter.outputs[0] | self.leftDelay | combiner.inputs[0]
-        splitter.outputs[1] | self.rightDelay | combiner.inputs[1]
-        combiner.output.connect(self.output)
+        split, join = AudioSplitter(nOutputs=STEREO), AudioCombiner(nInputs=STEREO)
+        self.input.connect(split.input)
+        for tap, delay, slot in zip(split.outputs, (self.leftDelay, self.rightDelay), join.inputs):
+            tap | delay | slot
+        join.output.connect(self.output)
         self.update_internal_exec_order()
 
 
@@ -254,22 +252,16 @@ class RingModulator(Composite):
 
     def __init__(self, frequency=500., rate=2., amount=20, wave_func=square, dryWet=1.):
         super().__init__()
-        self.inputs = [Input(owner=self), Input(owner=self), Relay(owner=self),
-                       Input(owner=self), Input(owner=self)]
+        self.frequency, self.rate, self.amount, self.dryWet = _value_ports(
+            self, (Input, frequency), (Relay, rate), (Input, amount), (Input, dryWet))
         self.outputs = [Relay(owner=self)]
-        _, self.frequency, self.rate, self.amount, self.dryWet = self.inputs
-        self.frequency.set_value(frequency)
-        self.rate.set_value(rate)
-        self.amount.set_value(amount)
-        self.dryWet.set_value(dryWet)
-        self.lfo = Oscillator(wave_func=wave_func)
-        self.modulator = Oscillator()
+        self.lfo, self.modulator = Oscillator(wave_func=wave_func), Oscillator()
         self.rate.connect(self.lfo.frequency)
 
     def update(self):
-        self.lfo.update()
-        freqs = self.frequency.value + self.amount.value * self.lfo.output.value
-        self.modulator.frequency.set_value(freqs)
+        self.lfo.update()       # sweeps the sine modulator's frequency, sample by sample
+        sweep = self.frequency.value + self.amount.value * self.lfo.output.value
+        self.modulator.frequency.set_value(sweep)
         self.modulator.update()
-        x = self.input.value
-        self.output.set_value(blend(x, self.modulator.output.value * x, self.dryWet.value))
+        dry = self.input.value
+        self.output.set_value(blend(dry, self.modulator.output.value * dry, self.dryWet.value))
