@@ -140,10 +140,16 @@ typedef enum {
     KLMI_FX_OCTAVE = 5,     /* OctaveDistortion (effects.py:452-466) */
     KLMI_FX_TREMOLO = 6,    /* Tremolo (effects.py:73-133): k0 rate (Hz), k1 depth,
                                k2 smoothness, k3 dutyCycle; state k0 lfo phase, k1 zi */
-    KLMI_FX_DELAY = 7,      /* Delay (effects.py:136-174): k0 time (s, <= 2; at least one
-                               buffer: 256 samples), k1 feedback, k2 drywet; state k0 ring
-                               position.  Setting k0 empties the lines of those voices whose
-                               length in samples changed; the others keep their contents. */
+    KLMI_FX_DELAY = 7,      /* Delay (effects.py:136-174): k0 time (s, <= 2, at least one
+                               sample), k1 feedback, k2 drywet; state k0 ring position.
+                               Setting k0 empties the lines of those voices whose length in
+                               samples changed; the others keep their contents.  Lines
+                               shorter than one buffer (256 samples) behave as the
+                               reference's RingBuffer does (ring_buffer.py:88-109: its tail
+                               and head copies land inside the window the Delay reads
+                               back); a bank with such a line runs the stage block by block
+                               (slower), and whether a bank has one is fixed by its first
+                               render. */
     KLMI_FX_SUBSAMPLE = 8,  /* Subsampler (effects.py:388-417): k0 factor, a power of 2 in 2..128 */
     KLMI_FX_BITCRUSH = 9,   /* Bitcrusher (effects.py:420-449): k0 nBits in 0..15; samples go
                                through int16 like convert_samples_to_int (wavfile.py:23-30) */

@@ -63,6 +63,10 @@ struct BankView {
     double *fx_ring;           // the delay stage's lines, [n][fx_ring_stride] (voice-major: ring
                                // positions differ per voice); slots [len, len+8) mirror [0, 8)
     int fx_ring_stride;
+    // some voice's delay line is shorter than one buffer: the lines are RingBuffer data arrays
+    // ([length slots][256 tail]) and the Delay runs block-major (mod_kernels.h delay_block)
+    int fx_block_major;
+    double *fx_stage;          // its staging area, [waves][2][256][64]
     // synthesizers: activity gating and device-side note routing
     int gated;                  // voices are only updated while Voice.active
     int poly;                   // voices per PolyphonicSynthesizer, 0: none

@@ -24,7 +24,7 @@ hipError_t upload_time_table_fx(const double *t)
 
 uint32_t fx_program_of(const BankView &view, bool filt, int mode)
 {
-    if (view.mod_target != MT_NONE || view.gated || view.poly != 0)
+    if (view.mod_target != MT_NONE || view.gated || view.poly != 0 || view.fx_block_major)
         return 0;
     if (mode != OUT_MIX_MONO && mode != OUT_MIX_STEREO && mode != OUT_VOICES_F64)
         return 0;

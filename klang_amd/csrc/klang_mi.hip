@@ -483,6 +483,10 @@ struct klmi_bank {
     int fx_ring_stride = 0;              // doubles per voice row: capacity + 8 mirror slots,
                                          // rounded up to whole 128-byte lines
     int fx_delay_stage = -1;
+    // some line is shorter than one buffer: lines are [length][256 tail], the Delay runs
+    // block-major through a staging area of [waves][2][256][64] doubles (mod_kernels.h)
+    bool fx_block_major = false;
+    DevBuf<double> fx_stage;
     DevBuf<double> lfo_par, mod_par;    // [3][n] frequency, scale, offset (allocated when used)
     DevBuf<int32_t> lfo_wave, mod_wave;
     // device state: one slab so that a preview can snapshot/restore it with two copies
@@ -589,6 +593,8 @@ static BankView make_view(klmi_bank *b)
     v.fx_state = b->desc.n_fx ? b->f64(SL_FX_STATE) : nullptr;
     v.fx_ring = b->fx_ring.p;
     v.fx_ring_stride = b->fx_ring_stride;
+    v.fx_block_major = b->fx_block_major ? 1 : 0;
+    v.fx_stage = b->fx_stage.p;
     v.gated = b->desc.gated || b->desc.poly_voices > 0;
     v.poly = b->desc.poly_voices;
     v.nt_offset = b->nt_offset.p;
@@ -703,9 +709,19 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
         return 0;
     const size_t n = (size_t)b->n;
     int need = 0;
-    for (size_t v = 0; v < n; ++v)
-        need = std::max(need, (int)(b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + v] *
-                                    KLMI_SAMPLING_RATE));
+    bool any_short = false;
+    for (size_t v = 0; v < n; ++v) {
+        const int len = (int)(b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + v] *
+                              KLMI_SAMPLING_RATE);
+        need = std::max(need, len);
+        any_short = any_short || len < KLMI_BUFFER_SIZE;
+    }
+    // The two line layouts (8 mirror slots / the RingBuffer's tail of one buffer) do not
+    // convert into each other once the lines hold samples.
+    if (b->fx_ring_cap > 0 && any_short != b->fx_block_major)
+        return fail(KLMI_E_STATE, "Delay times shorter than one buffer (%d samples) have to be set "
+                                  "before the bank's first render, for all voices at once, and "
+                                  "cannot be left again later", KLMI_BUFFER_SIZE);
     if (need <= b->fx_ring_cap) {
         b->fx_ring_dirty = false;
         return 0;
@@ -714,7 +730,15 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
         return fail(KLMI_E_STATE, "the Delay stage's lines are not allocated yet (or a longer "
                                   "time was set): one allocating render (or preview) must come first");
     hipStream_t st = b->ctx->stream;
-    const int stride = (need + 8 + 15) & ~15;
+    const int stride = (need + (any_short ? KLMI_BUFFER_SIZE : 8) + 15) & ~15;
+    if (any_short && !b->fx_stage.p) {
+        const size_t waves = ((size_t)b->n + kGroup - 1) / kGroup * kWavesPerGroup;
+        hipError_t se = b->fx_stage.alloc(waves * 2 * kBlock * 64);
+        if (se != hipSuccess)
+            return fail(KLMI_E_MEMORY, "the block-major Delay's staging area (%zu MiB) does not fit: %s",
+                        (waves * 2 * kBlock * 64 * sizeof(double)) >> 20, hipGetErrorString(se));
+    }
+    b->fx_block_major = any_short;
     DevBuf<double> grown;
     hipError_t e = grown.alloc((size_t)stride * n);
     if (e != hipSuccess)
@@ -1027,9 +1051,9 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
             for (int i = 0; i < count; ++i) {
                 if (host[i] > 2.)  // effects.py:140, 160-164
                     return fail(KLMI_E_ARG, "Delay time %.3f sec to long (max %.3f)!", host[i], 2.);
-                if (!((int)(host[i] * KLMI_SAMPLING_RATE) >= KLMI_BUFFER_SIZE))
+                if (!((int)(host[i] * KLMI_SAMPLING_RATE) >= 1))
                     return fail(KLMI_E_ARG, "klmi_bank_set_params: delay time %g s is shorter than "
-                                            "one buffer (%d samples)", host[i], KLMI_BUFFER_SIZE);
+                                            "one sample", host[i]);
             }
         }
         if (b->desc.fx[stage] == KLMI_FX_SUBSAMPLE && k == 0) {

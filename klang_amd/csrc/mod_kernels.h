@@ -300,6 +300,45 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
         delay_len = (int)par[0];
         delay_fb = par[n], delay_dw = par[2 * n];
     }
+    // Delay lines shorter than one buffer (bk.fx_block_major, set for the whole bank when any
+    // voice has one): RingBuffer.extend's tail and head copies then land inside the window
+    // Delay.update reads back (ring_buffer.py:88-109, effects.py:166-174), so the stage's
+    // output at sample i can be a value from LATER in the same buffer.  The buffer is then
+    // handled in two passes around a block-level Delay: pass 1 runs the voice and the stages
+    // in front of the Delay for all 256 samples into a per-wave staging area in global memory
+    // ([256][64 lanes] float64, two planes), delay_block() does what the reference does with
+    // whole buffers, pass 3 runs the remaining stages and the mix-down.  Lines are the
+    // RingBuffer's data array here: `length` slots and a tail of one buffer.
+    const bool block_major = HAS_FX && bk.fx_block_major != 0 && delay_stage >= 0;
+    double *stage_new = nullptr, *stage_val = nullptr;
+    if (block_major) {
+        stage_new = bk.fx_stage + (size_t)(blockIdx.x * kWavesPerGroup + wave) * 2 * kBlock * 64;
+        stage_val = stage_new + kBlock * 64;
+    }
+    auto delay_block = [&]() {
+        const int start = delay_pos, stop = start + kBlock;
+        for (int i = 0; i < kBlock; ++i)     // new + feedback * peek()
+            stage_val[i * 64 + lane] = stage_new[i * 64 + lane] + delay_fb * delay_line[start + i];
+        if (live) {
+            for (int i = 0; i < kBlock; ++i)                 // ring_buffer.py:95-97
+                delay_line[start + i] = stage_val[i * 64 + lane];
+            if (start < kBlock) {                            // :98-102, the tail
+                const int a = start + delay_len, cnt = kBlock - start;
+                for (int k = 0; k < cnt; ++k)
+                    delay_line[a + k] = stage_val[k * 64 + lane];
+            }
+            if (stop > delay_len) {                          // :104-108, the head
+                const int a = start > delay_len ? start - delay_len : 0;
+                const int cnt = stop - delay_len - a;
+                for (int k = 0; k < cnt; ++k)
+                    delay_line[a + k] = stage_val[(kBlock - cnt + k) * 64 + lane];
+            }
+        }
+        for (int i = 0; i < kBlock; ++i) {   // blend(new, the window after the writes)
+            const double nw = stage_new[i * 64 + lane];
+            stage_new[i * 64 + lane] = (1. - delay_dw) * nw + delay_dw * delay_line[start + i];
+        }
+    };
     unsigned long long fx_kinds = 0;   // stage kinds, one byte each (scalar)
 #pragma unroll
     for (int s = 0; s < 8; ++s)
@@ -487,6 +526,14 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
             }
         };
 
+        // pass 0: the whole chain, chunk by chunk.  Block-major Delay: pass 1 (voice and the
+        // stages in front of the Delay -> staging), delay_block(), pass 3 (staging -> the
+        // remaining stages -> mix-down)
+        const int n_pass = block_major ? 2 : 1;
+        for (int pi = 0; pi < n_pass; ++pi) {
+        const int pass = block_major ? (pi == 0 ? 1 : 3) : 0;
+        const int s_begin = pass == 3 ? delay_stage + 1 : 0;
+        const int s_end = pass == 1 ? delay_stage : n_fx;
         for (int c = 0; c < NCHUNK; ++c) {
             const int s0 = b * kBlock + c * CH;
             const double *times = c_time + c * CH;
@@ -559,13 +606,18 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                         strip[(i + j) * 64 + lane] = x[j];
                 };
                 for (int half = 0; half < CH; half += SUB) {
-                    for (int i8 = half; i8 < half + SUB; i8 += G) {
-                        double x[G];
-                        voice_group(i8, x);
-                        store_x(i8 - half, x);
+                    if (pass != 3) {
+                        for (int i8 = half; i8 < half + SUB; i8 += G) {
+                            double x[G];
+                            voice_group(i8, x);
+                            store_x(i8 - half, x);
+                        }
+                    } else {
+                        for (int i = 0; i < SUB; ++i)
+                            strip[i * 64 + lane] = stage_new[(c * CH + half + i) * 64 + lane];
                     }
 #pragma nounroll
-                    for (int s = 0; s < n_fx; ++s) {
+                    for (int s = s_begin; s < s_end; ++s) {
                         const double p0 = bk.fx_par[(size_t)(s * kFxSlots) * n + v];
                         switch ((int)((fx_kinds >> (8 * s)) & 0xFFu)) {
                         case FX_FILTER: {
@@ -761,6 +813,11 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             break;
                         }
                     }
+                    if (pass == 1) {
+                        for (int i = 0; i < SUB; ++i)
+                            stage_new[(c * CH + half + i) * 64 + lane] = strip[i * 64 + lane];
+                        continue;
+                    }
                     for (int i8 = half; i8 < half + SUB; i8 += G) {
                         double x[G];
                         load_x(i8 - half, x);
@@ -770,7 +827,11 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                     }
                 }
             }
-            flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
+            if (pass != 1)
+                flush_chunk<MODE>(tile, lane, wave, b, c, n_blocks, count, span_total, s0, partial, out);
+        }
+        if (pass == 1)
+            delay_block();
         }
         // next start phases: sample 256 of this block
         if (trem_stage >= 0)

@@ -124,8 +124,6 @@ class Chain:
                 raise NotFusable('%s: Lfo wave function %r has no device twin'
                                  % (stage, stage.lfo.wave_func))
         if kind is Delay:
-            if stage.ring.length < BUFFER_SIZE:
-                raise NotFusable('%s: delay lines shorter than one buffer are not fused' % stage)
             if stage.ring.data.any():
                 raise NotFusable('%s: its delay line already holds samples' % stage)
 

@@ -614,20 +614,38 @@ static void ko_voice_block(ko_bank *bk, int v, double *buf /* 256 */)
             }
             break;
         }
-        case KO_FX_DELAY: { /* effects.py:166-174 + ring_buffer.py:62-107.  The window that
-            peek() returns is a view, so after extend() it holds new + feedback * old and
-            the blend's wet operand is that sum.  Valid while length >= one buffer. */
+        case KO_FX_DELAY: { /* effects.py:166-174 + ring_buffer.py:62-109, for any length >= 1.
+            The line is the RingBuffer's data array: `length` slots and a tail of one buffer.
+            peek() returns a VIEW of data[pos : pos + 256]; extend() then writes the new
+            values there, copies those that fall into the first buffer's worth of slots to the
+            tail and those that run over the end to the head -- three slice assignments in
+            this order -- and the blend reads the view afterwards.  For length >= 256 that is
+            "wet = new + feedback * delayed"; for shorter lines the copies land inside the
+            window (fixtures delay_short_* from the real reference). */
             const int length = (int)(par[0] * KO_SAMPLING_RATE);
             const double feedback = par[n], drywet = par[2 * n];
             double *ring = bk->fx_ring + (size_t)v * bk->fx_ring_capacity;
-            int pos = (int)state[0];
-            for (int i = 0; i < KO_BUFFER_SIZE; ++i) {
-                const int idx = (pos + i) % length;
-                const double w = buf[i] + feedback * ring[idx];
-                ring[idx] = w;
-                buf[i] = (1. - drywet) * buf[i] + drywet * w; /* math.py:68-75 blend */
+            const int start = (int)state[0], stop = start + KO_BUFFER_SIZE;
+            double values[KO_BUFFER_SIZE];
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i)
+                values[i] = buf[i] + feedback * ring[start + i];
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i) /* ring_buffer.py:95-97 */
+                ring[start + i] = values[i];
+            if (start < KO_BUFFER_SIZE) { /* ring_buffer.py:98-102: copy to the tail */
+                const int a = start + length;
+                const int b = length + KO_BUFFER_SIZE < stop + length ? length + KO_BUFFER_SIZE : stop + length;
+                for (int k = 0; k < b - a; ++k)
+                    ring[a + k] = values[k];
             }
-            state[0] = (double)((pos + KO_BUFFER_SIZE) % length);
+            if (stop > length) { /* ring_buffer.py:104-108: copy to the head */
+                const int a = start - length > 0 ? start - length : 0;
+                const int b = stop - length;
+                for (int k = 0; k < b - a; ++k)
+                    ring[a + k] = values[KO_BUFFER_SIZE - (b - a) + k];
+            }
+            state[0] = (double)(stop % length);
+            for (int i = 0; i < KO_BUFFER_SIZE; ++i) /* math.py:68-75 blend(new, view) */
+                buf[i] = (1. - drywet) * buf[i] + drywet * ring[start + i];
             break;
         }
         case KO_FX_SUBSAMPLE: { /* effects.py:400-415: np.repeat(x[::skip], skip) */

@@ -414,9 +414,10 @@ class OracleBank:
                 self.fx_par[s, k, :] = p
             if st[0] == FX_DELAY:
                 lengths = (self.fx_par[s, 0] * 44100).astype(int)
-                if lengths.min() < BUFFER_SIZE:
-                    raise ValueError('delay shorter than one buffer')
-                self.fx_ring = np.zeros((self.n, int(lengths.max())))
+                if lengths.min() < 1:
+                    raise ValueError('empty delay line')
+                # the RingBuffer's data array: the line and one buffer of tail (ring_buffer.py:38-42)
+                self.fx_ring = np.zeros((self.n, int(lengths.max()) + BUFFER_SIZE))
 
     def set_envelope(self, i, attack, decay, sustain, release, overshoot=1e-3, retrigger=False,
                      loop=False):

@@ -198,6 +198,65 @@ def test_compiled_effect_program_under_a_stereo_mixer(hip, ctx, oracle):
     hb.close()
 
 
+@pytest.mark.parametrize('length', [100, 200, 255, 17])
+def test_delay_lines_shorter_than_a_buffer_vs_reference(hip, ctx, golden, length):
+    """int(time * 44100) < 256 (fixtures delay_short_* from the real reference): the bank runs
+    the Delay block by block with the RingBuffer's own data layout (mod_kernels.h delay_block)."""
+    want = golden('effects_patched')['delay_short_%d' % length]
+    nb = len(want)
+    bank = saw_bank(hip, ctx, [(hip.FX_DELAY, (length + .5) / 44100., .6, .4)])
+    got = bank.render_voices(nb, f64=True)[0].reshape(nb, B)
+    np.testing.assert_array_equal(got, want)
+    mix = np.concatenate([bank.render(5), bank.render(nb - 5)])[:, 0, :]
+    assert report('effect: delay (line shorter than a buffer)', np.abs(mix - want).max()) <= 1e-5
+    assert bank.get_state(hip.F_FX_STATE(0, 0))[0] == (nb * B) % length
+    bank.close()
+
+
+@pytest.mark.parametrize('stereo', [False, True])
+def test_short_and_long_delay_lines_in_one_bank_vs_oracle(hip, ctx, oracle, stereo):
+    """Filter -> Tremolo -> Delay -> Gain over 300 voices whose lines run from 3 to 900 samples
+    (a third of them shorter than a buffer): float64 streams, positions and filter state equal
+    the oracle's bit for bit, over split launches; and a bank that has rendered with long
+    lines only refuses a short one afterwards."""
+    n, nb = 300, 10
+    rng = np.random.default_rng(51)
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=5)
+    patch['stereo'] = stereo
+    patch['pan'] = 2. * rng.random(n) - 1.
+    lengths = rng.integers(256, 900, n)
+    lengths[::3] = rng.integers(3, 256, len(lengths[::3]))
+    stages = [(hip.FX_FILTER,),
+              (hip.FX_TREMOLO, 1. + 9. * rng.random(n), rng.random(n), rng.random(n), .1 + .8 * rng.random(n)),
+              (hip.FX_DELAY, (lengths + .5) / 44100., .9 * rng.random(n), rng.random(n)),
+              (hip.FX_GAIN, rng.random(n))]
+    table, grid = library_table(hip)
+    from tests.helpers import oracle_bank_from_patch
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.set_effects(stages)
+    hb = hip.Bank(ctx, n, has_env=True, has_filter=True, stereo=stereo, effects=[s[0] for s in stages])
+    hb.load_patch(patch)
+    for s, st in enumerate(stages):
+        for k, p in enumerate(st[1:]):
+            hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+    np.testing.assert_array_equal(hb.render_voices(nb, f64=True), want_voices)
+    mix = np.concatenate([hb.render(3), hb.render(7)])
+    assert np.abs(want_mix).max() > 1e-3 and np.abs(mix - want_mix).max() <= 1e-6
+    np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(2, 0)), ob.fx_state[2, 0])
+    np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(1, 1)), ob.fx_state[1, 1])
+    np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
+    hb.close()
+    if not stereo:
+        late = saw_bank(hip, ctx, [(hip.FX_DELAY, .01, .5, .5)], n=2)
+        late.render(1)
+        late.set(hip.F_FX(0, 0), [.001, .01])
+        with pytest.raises(hip.NativeError) as e:
+            late.render(1)
+        assert 'before the bank' in str(e.value)
+        late.close()
+
+
 def test_crusher_and_ring_modulator_vs_oracle_many_voices(hip, ctx, oracle):
     """600 voices through Gain -> Bitcrusher -> RingModulator(non-sine Lfo) -> Subsampler ->
     Filter with per-voice parameters; Gain up to 1.5 so that the int16 wrap of the crusher
@@ -266,7 +325,7 @@ def test_effect_argument_errors(hip, ctx):
         bank.set(hip.F_FX(1, 0), [2.5, 1.])
     assert 'to long' in str(e.value)                                    # effects.py:160-164
     with pytest.raises(hip.NativeError):
-        bank.set(hip.F_FX(1, 0), [.001, 1.])                            # shorter than a buffer
+        bank.set(hip.F_FX(1, 0), [.00001, 1.])                          # shorter than a sample
     with pytest.raises(hip.NativeError):
         bank.set(hip.F_FX(2, 0), [1., 1.])                              # no such stage
     with pytest.raises(hip.NativeError):

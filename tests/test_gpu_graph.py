@@ -303,13 +303,22 @@ def _effect_patches():
             mixer += voice | Filter(frequency=900.) | trem | gain
         return mixer | Dac()
 
+    def short_delays():       # delay lines shorter than one buffer (comb / flanger territory)
+        mixer = Mixer()
+        for k in range(4):
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.01, .05, .6, .04))
+            voice.input.push(Note(0, .8, frequency=123.5 * (k + 1)))
+            mixer += voice | Filter(frequency=1200.) | Delay(time=(.0004, .002, .0057, .02)[k], feedback=.7) | Gain(.7)
+        return mixer | Dac()
+
     return dict(arpeggiator_like=arpeggiator_like, tremolo_chain=tremolo_chain, shaping=shaping,
                 lofi=lofi, stereo_stages=stereo_stages, stages_into_reverb=stages_into_reverb,
-                patched_parameters=patched_parameters)
+                patched_parameters=patched_parameters, short_delays=short_delays)
 
 
 @pytest.mark.parametrize('name', ['arpeggiator_like', 'tremolo_chain', 'shaping', 'lofi',
-                                  'stereo_stages', 'stages_into_reverb', 'patched_parameters'])
+                                  'stereo_stages', 'stages_into_reverb', 'patched_parameters',
+                                  'short_delays'])
 def test_effect_patches_match_the_host_evaluation(hip, name):
     build = _effect_patches()[name]
     order, banks = fusion.compile_order(determine_execution_order([build()]))

@@ -305,8 +305,8 @@ def test_fuser_recognises_effect_stages():
     assert not errors and len(groups) == 2
     tail = [c for _, (c,), _ in groups if c.external is not None]
     assert len(tail) == 1 and tail[0].external is rv.output and tail[0].program == (native.FX_GAIN,)
-    # refused: two delays, a gain modulated at audio rate, a short delay; a gain driven at
-    # block rate by a host Lfo is fused (the Lfo stays a host block)
+    # refused: two delays, a gain modulated at audio rate; a gain driven at block rate by a
+    # host Lfo is fused (the Lfo stays a host block), and so is a delay shorter than a buffer
     two = Oscillator() | Delay(.01) | Delay(.02)
     _, errors = fusion.find_fusable(determine_execution_order([two]))
     assert any('one Delay per chain' in e for e in errors)
@@ -318,8 +318,8 @@ def test_fuser_recognises_effect_stages():
     Oscillator(3.) | gain.gain
     _, errors = fusion.find_fusable(determine_execution_order([Oscillator() | gain]))
     assert any('audio rate' in e for e in errors)
-    _, errors = fusion.find_fusable(determine_execution_order([Oscillator() | Delay(.001)]))
-    assert any('shorter than one buffer' in e for e in errors)
+    groups, errors = fusion.find_fusable(determine_execution_order([Oscillator() | Delay(.001)]))
+    assert not errors and groups[0][1][0].program == (native.FX_DELAY,)   # 44 samples: block-major
     trem = Oscillator() | Tremolo(rate=4.)
     groups, errors = fusion.find_fusable(determine_execution_order([trem]))
     assert not errors and groups[0][1][0].program == (native.FX_TREMOLO,)

@@ -525,6 +525,17 @@ def test_effect_stage(oracle, golden, key, stage, n_blocks, tol):
             assert bank.fx_state[0, 0, 0] == g[key + '_final'][0]
 
 
+@pytest.mark.parametrize('length', [100, 200, 255, 17])
+def test_delay_lines_shorter_than_a_buffer(oracle, golden, length):
+    """int(time * 44100) < 256 (tools/gen_golden.py: the real reference's Delay on a saw): the
+    RingBuffer's tail and head copies land inside the window the blend reads back."""
+    want = golden('effects_patched')['delay_short_%d' % length]
+    bank = _fx_bank(oracle, golden, [(oracle.FX_DELAY, (length + .5) / 44100., .6, .4)])
+    mix, _ = bank.render(len(want))
+    eq(mix[:, 0, :], want)
+    assert bank.fx_state[0, 0, 0] == (len(want) * 256) % length
+
+
 def test_bitcrusher_wraps_like_the_reference(oracle):
     """|x| > 1 overflows int16 in convert_samples_to_int (wavfile.py:23-30): the C cast keeps
     the low 16 bits; checked against the value the real reference returned for x = -1.2 .. 1.2
