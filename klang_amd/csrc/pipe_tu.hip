@@ -8,7 +8,7 @@ namespace klmi {
 
 int pipe_voices_log2(const BankView &view, bool filt, int count, int mode, int n_cus)
 {
-    static const int forced = [] {
+    const int forced = [] {   // read per call: the parity tests switch it inside one process
         const char *e = getenv("KLMI_PIPE_VOICES_LOG2");   // tuning knob: -1 switches it off
         return e ? atoi(e) : -2;
     }();
