@@ -482,6 +482,29 @@ def test_full_size_config3_properties(hip, ctx, oracle):
     np.testing.assert_array_equal(full.get_state(hip.F_PHASE), ob.phase)
 
 
+def test_full_size_config3_long_run_vs_oracle(hip, ctx, oracle):
+    """65,536 voices x 48 buffers (every envelope stage visited: notes end between buffers 8
+    and 40) in launches of 1 + 20 + 27 buffers: the mix and every voice's final phase, envelope
+    and filter state against the threaded oracle."""
+    n, nb = 65536, 48
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=8, off_span=32)
+    table, grid = library_table(hip)
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    want, _ = ob.render(nb, patch.events, n_threads=min(16, oracle.max_threads()))
+    bank = hip_bank_from_patch(hip, ctx, patch)
+    mix = np.concatenate([bank.render(1), bank.render(20), bank.render(27)])
+    err = np.abs(mix[:, 0, :] - want[:, 0, :]).max()
+    report('chain osc+ADSR+biquad+mixer (65,536 voices, 48 buffers)', err)
+    assert err <= 1e-6 and np.abs(want).max() > 1e-3
+    stage, value, enabled = ob.env_state()
+    assert len(set(stage.tolist())) >= 2          # some voices still sound, others are off
+    np.testing.assert_array_equal(bank.get_state(hip.F_PHASE), ob.phase)
+    np.testing.assert_array_equal(bank.get_state(hip.F_ENV_VALUE), value)
+    np.testing.assert_array_equal(bank.get_state(hip.F_ENV_STAGE), stage)
+    np.testing.assert_array_equal(bank.get_state(hip.F_Z0), ob.z0)
+    np.testing.assert_array_equal(bank.get_state(hip.F_Z1), ob.z1)
+
+
 def test_render_device_is_ordered_on_the_callers_stream(hip, ctx):
     """klmi_ctx_create(stream=NULL) is the default stream: a torch copy issued
     right after render_device, with no synchronisation in between, sees the bus."""
