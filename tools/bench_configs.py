@@ -118,7 +118,10 @@ def config3_general(ctx, label, **bank_kw):
     best, med = timed(lambda: bank.render(n_blocks))
     ms, launches = bank.last_kernel_ms()
     units = n * n_blocks * B
-    return dict(config='3 general kernel, %s: 65,536 voices x %d blocks' % (label, n_blocks),
+    kernel = ('general kernel (KLMI_FM_KERNEL / KLMI_FX_KERNEL = 0)'
+              if '0' in (os.environ.get('KLMI_FM_KERNEL'), os.environ.get('KLMI_FX_KERNEL'))
+              else 'FM form of the fast kernel' if bank_kw.get('mod_target') else 'compiled stage program')
+    return dict(config='3 with %s, %s: 65,536 voices x %d blocks' % (label, kernel, n_blocks),
                 value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
                 launches=launches)
 
