@@ -277,7 +277,13 @@ __device__ __forceinline__ void lfo_cutoff_step(const BankView &bk, int v, doubl
 // that sum) under the same single check; wavefronts whose carrier and modulator do not share
 // one of sine / square / sawtooth / triangle (the reference builds both from one wave_func)
 // take the exact per-sample form.
-template <bool ENV, bool FILT, int MODE, bool GATED = false, bool FM = false>
+// MOD = MT_FREQUENCY / MT_DUTY: an Lfo(shape=256) patched into Oscillator.frequency (the
+// np.cumsum branch of sample_phase, oscillators.py:61-64: phase[n] = (TAU*DT) * sum(f[0..n-1])
+// + start) or PwmOscillator.dutyCycle (oscillators.py:256-260).  The Lfo's eight values are a
+// region of their own in front of the straight-line region (independent samples, the wave
+// function chosen by one scalar jump, the remainder repaired in place); the running frequency
+// sum is one more serial recurrence -- a single add per sample -- beside envelope and biquad.
+template <bool ENV, bool FILT, int MODE, bool GATED = false, int MOD = MT_NONE>
 __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, int count,
                                                        int block_base,      // first block, relative to this call
                                                        uint32_t clock_base,  // absolute number of block_base (events)
@@ -292,6 +298,8 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     constexpr int NCHUNK = kBlock / CH;
     constexpr int PLANES = TT::planes;
     constexpr bool MIX = (MODE == OUT_MIX_MONO || MODE == OUT_MIX_STEREO);
+    constexpr bool FM = MOD == MT_FM, VIB = MOD == MT_FREQUENCY, PWMOD = MOD == MT_DUTY;
+    constexpr bool LFO = VIB || PWMOD;   // the modulator is an audio-rate Lfo with scale / offset
 
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -313,15 +321,19 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     const int first_wave = __builtin_amdgcn_readfirstlane(wave_id);
     const int uniform_wave = __all(wave_id == first_wave) ? first_wave : -1;
     double phase = bk.phase[v];
-    static_assert(!(FM && GATED), "gated FM chains run in voice_mod_kernel");
-    double mod_freq = 0., mod_scale = 0., mod_phase = 0.;
+    static_assert(!(MOD != MT_NONE && GATED), "gated modulated chains run in voice_mod_kernel");
+    double mod_freq = 0., mod_scale = 0., mod_offset = 0., mod_phase = 0.;
     int mod_wave = 0;
     bool fm_paired = false;  // wave-uniform: carrier and modulator share a plain wave function
-    if (FM) {
+    int uniform_mod_wave = -1;  // the Lfo's wave function when the whole wavefront agrees on it
+    if (MOD != MT_NONE) {
         mod_freq = bk.mod_par[v], mod_scale = bk.mod_par[(size_t)bk.n + v];
+        mod_offset = bk.mod_par[2 * (size_t)bk.n + v];
         mod_wave = bk.mod_wave[v];
         mod_phase = bk.mod_phase[v];
         fm_paired = uniform_wave >= W_SINE && uniform_wave <= W_TRIANGLE && __all(mod_wave == wave_id);
+        const int first_mod_wave = __builtin_amdgcn_readfirstlane(mod_wave);
+        uniform_mod_wave = __all(mod_wave == first_mod_wave) ? first_mod_wave : -1;
     }
 
     EnvParams ep;
@@ -472,6 +484,65 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
             fast_block = fast_block && fm_paired &&
                          __all(mod_omega >= 0. && mod_start >= 0. &&
                                mod_omega * c_time[kBlock] + mod_start < 1e9 && fabs(mod_scale) < 1e8);
+        if (VIB)  // the phase is a running sum of Lfo values: bounded by the Lfo's range
+            fast_block = __all(start >= 0. && (kTau * kDt) * kBlock * (fabs(mod_scale) + fabs(mod_offset)) +
+                                                      start < 1e9);
+        // the Lfo's own phase: non-negative and bounded, one plain wave function per wavefront
+        const bool fast_mod = LFO && uniform_mod_wave >= W_SINE && uniform_mod_wave <= W_TRIANGLE &&
+                              __all(mod_omega >= 0. && mod_start >= 0. &&
+                                    mod_omega * c_time[kBlock] + mod_start < 1e9);
+        double running = 0.;   // np.cumsum(frequency) within this block (VIB)
+        // Lfo.sample for eight time points (oscillators.py:175-190): scale * wave(phase) + offset
+        auto lfo_group = [&](const Time8 &tt, double (&m)[8]) {
+            double marg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                marg[j] = mod_omega * tt.t[j] + mod_start;
+            if (fast_mod) {
+                double mp[8];
+                uint32_t hi_max = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double k = floor(marg[j] * kInvTau);
+                    mp[j] = __builtin_fma(-k, kTau, marg[j]);
+                    hi_max = max(hi_max, (uint32_t)__double2hiint(mp[j]));
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) != 0, 0)) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        mp[j] = fmod_tau_fast(marg[j]);
+                }
+                switch (uniform_mod_wave) {
+                case W_SINE:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        m[j] = wave_eval<true>(W_SINE, mp[j], kPi);
+                    break;
+                case W_SQUARE:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        m[j] = wave_eval<true>(W_SQUARE, mp[j], kPi);
+                    break;
+                case W_SAWTOOTH:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        m[j] = wave_eval<true>(W_SAWTOOTH, mp[j], kPi);
+                    break;
+                default:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        m[j] = wave_eval<true>(W_TRIANGLE, mp[j], kPi);
+                    break;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    m[j] = wave_eval<false>(mod_wave, np_mod_tau(marg[j]), kPi);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                m[j] = mod_scale * m[j] + mod_offset;
+        };
         // FmOscillator.sample, exactly, for one time point (oscillators.py:215-220)
         auto fm_sample = [&](int w, double t) {
             const double mp = np_mod_tau(mod_omega * t + mod_start);
@@ -496,6 +567,10 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                 auto group8 = [&](int i8, const Time8 &tt) {
                     constexpr int G = 8;
                     const int wsel = (WK >= 0) ? WK : wave_id;
+                    double m[G];   // the Lfo's values (LFO)
+                    if constexpr (LFO)
+                        lfo_group(tt, m);
+                    const bool first_group = c == 0 && i8 == 0;
                     // Eight samples as ONE straight-line region: oscillator (8 independent
                     // samples), envelope and biquad recurrences (serial chains) are all
                     // computed speculatively so that the scheduler can interleave the chains
@@ -526,7 +601,21 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
 #pragma unroll
                         for (int j = 0; j < G; ++j) {
                             arg[j] = omega * tt.t[j] + start;  // oscillators.py:60
-                            if constexpr (FM && FAST) {
+                            if constexpr (VIB) {
+                                // oscillators.py:61-64: phase[0] = start, phase[n] = (TAU*DT) *
+                                // cumsum(f)[n-1] + start; np.cumsum is a sequential float64 sum
+                                const bool first = first_group && j == 0;
+                                arg[j] = first ? start : (kTau * kDt) * running + start;
+                                running = first ? m[j] : running + m[j];
+                            }
+                            if constexpr (PWMOD && FAST) {          // oscillators.py:259-260
+                                const double k = floor(arg[j] * kInvTau);
+                                const double ph = __builtin_fma(-k, kTau, arg[j]);
+                                hi_max = max(hi_max, (uint32_t)__double2hiint(ph));
+                                osc[j] = (ph < kTau * m[j]) ? 1. : -1.;
+                            } else if constexpr (PWMOD) {
+                                osc[j] = (np_mod_tau(arg[j]) < kTau * m[j]) ? 1. : -1.;
+                            } else if constexpr (FM && FAST) {
                                 // modulator: Oscillator.sample of the same wave function
                                 const double marg = mod_omega * tt.t[j] + mod_start;
                                 const double mk = floor(marg * kInvTau);
@@ -603,6 +692,12 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                             double x = osc[j];
                             if constexpr (FM && FAST) {
                                 x = fm_sample(wsel, tt.t[j]);
+                            } else if constexpr (VIB && FAST) {   // a negative phase argument lands here
+                                if (has_phase)
+                                    x = wave_eval<false>(wsel, np_mod_tau(arg[j]), duty_edge);
+                            } else if constexpr (PWMOD && FAST) {
+                                if (has_phase)
+                                    x = (fmod_tau_fast(arg[j]) < kTau * m[j]) ? 1. : -1.;
                             } else if constexpr (FAST) {
                                 if (has_phase)
                                     x = wave_eval<true>(wsel, fmod_tau_fast(arg[j]), duty_edge);
@@ -651,7 +746,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
                     run_chunk(integral_constant<int, -1>{}, std::false_type{}, unit);
                 }
             };
-            if constexpr (MODE == OUT_MIX_MONO && !FM) {
+            if constexpr (MODE == OUT_MIX_MONO && MOD == MT_NONE) {
                 if (unit_gain)
                     dispatch(std::true_type{});
                 else
@@ -663,8 +758,9 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
         }
         // oscillators.py:66-67: next start phase is sample 256 of this block
         if (wave_id != W_EXTERNAL && wave_id != W_ONE)
-            phase = np_mod_tau(omega * c_time[kBlock] + start);
-        if (FM)
+            phase = VIB ? np_mod_tau((kTau * kDt) * running + start)
+                        : np_mod_tau(omega * c_time[kBlock] + start);
+        if (MOD != MT_NONE)
             mod_phase = np_mod_tau(mod_omega * c_time[kBlock] + mod_start);
         if (GATED && !run)
             phase = start;
@@ -673,7 +769,7 @@ __global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, i
     // ---- store state ----------------------------------------------------------------
     if (live) {
         bk.phase[v] = phase;
-        if (FM)
+        if (MOD != MT_NONE)
             bk.mod_phase[v] = mod_phase;
         bk.frequency_rw[v] = freq;
         bk.amplitude_rw[v] = amp;

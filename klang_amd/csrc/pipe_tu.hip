@@ -21,7 +21,7 @@ int pipe_voices_log2(const BankView &view, bool filt, int count, int mode, int n
     // Measured on MI355X (256 CUs): against one lane per voice the pipeline wins
     // up to about 18,000 voices for chains with a biquad (its serial chain is the longer
     // one) and 24,000 without; beyond that the one-lane kernel has enough waves.
-    static const int per_cu = [] {
+    const int per_cu = [] {
         const char *e = getenv("KLMI_PIPE_GROUPS_PER_CU");   // tuning knob
         const int v = e ? atoi(e) : 0;
         return v >= 1 && v <= 64 ? v : 3;
@@ -45,7 +45,7 @@ int pipe_voices_log2(const BankView &view, bool filt, int count, int mode, int n
 // many, so that every compute unit carries the same number of voices.
 int pipe_groups(int count, int l, int n_cus, int *n_big)
 {
-    static const bool split = [] {
+    const bool split = [] {
         const char *e = getenv("KLMI_PIPE_SPLIT");   // tuning knob: 0 = equal workgroups
         return !(e && e[0] == '0');
     }();

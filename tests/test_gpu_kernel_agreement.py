@@ -62,7 +62,7 @@ def assert_same(a, b):
 @pytest.mark.parametrize('seed', range(6))
 def test_plain_chains_lane_per_voice_vs_pipelined(hip, ctx, monkeypatch, seed):
     rng = np.random.default_rng(100 + seed)
-    n = int(rng.choice([1, 20, 63, 200, 1000, 3000]))
+    n = int(rng.choice([1, 20, 63, 200, 1000, 3000, 5000]))
     nb = int(rng.integers(3, 9))
     patch = random_patch(rng, n, nb, has_filter=bool(seed & 1), stereo=bool(seed & 2))
     split = int(rng.integers(1, nb))
@@ -73,19 +73,35 @@ def test_plain_chains_lane_per_voice_vs_pipelined(hip, ctx, monkeypatch, seed):
         assert_same(outcome(hip, ctx, patch, nb, split), want)
     monkeypatch.delenv('KLMI_PIPE_VOICES_LOG2')
     assert_same(outcome(hip, ctx, patch, nb, split), want)      # the library's own choice
+    monkeypatch.setenv('KLMI_PIPE_SPLIT', '0')                  # ... with equal workgroups
+    assert_same(outcome(hip, ctx, patch, nb, split), want)
 
 
+@pytest.mark.parametrize('target', ['MOD_FM', 'MOD_FREQUENCY', 'MOD_DUTY'])
 @pytest.mark.parametrize('seed', range(4))
-def test_fm_fast_form_vs_general_kernel(hip, ctx, monkeypatch, seed):
+def test_modulated_fast_forms_vs_general_kernel(hip, ctx, monkeypatch, seed, target):
+    """FmOscillator, Lfo(256) -> frequency and Lfo(256) -> duty cycle: the fast kernel's forms
+    against voice_mod_kernel (KLMI_FM_KERNEL=0), wavefronts that agree on the Lfo's wave
+    function and wavefronts that do not, a few negative Lfo frequencies."""
     rng = np.random.default_rng(200 + seed)
     n, nb = int(rng.choice([5, 130, 700])), 6
-    patch = random_patch(rng, n, nb, has_filter=bool(seed & 1), stereo=False)
-    same = rng.random() < .5
-    fields = [(hip.F_MOD_FREQUENCY, 1. + 300. * rng.random(n)), (hip.F_MOD_SCALE, 8. * rng.random(n) - 4.),
-              (hip.F_MOD_WAVE, patch['wave'] if same else rng.integers(0, 4, n))]
+    patch = random_patch(rng, n, nb, has_filter=bool(seed & 1), stereo=bool(seed & 2))
+    tgt = getattr(hip, target)
+    if tgt == hip.MOD_DUTY:
+        patch['wave'] = np.full(n, P.WAVE_PWM, dtype=np.int32)
+    mod_wave = np.asarray(patch['wave']) if (tgt == hip.MOD_FM and rng.random() < .5) else rng.integers(0, 4, n)
+    if tgt != hip.MOD_FM and seed & 1:
+        mod_wave = np.repeat(rng.integers(0, 4, -(-n // 64)), 64)[:n]
+    mod_freq = 1. + 300. * rng.random(n)
+    mod_freq[::37] = -mod_freq[::37]
+    scale, offset = {hip.MOD_FM: (8. * rng.random(n) - 4., np.zeros(n)),
+                     hip.MOD_FREQUENCY: (40. * rng.random(n), np.asarray(patch['frequency'], dtype=float)),
+                     hip.MOD_DUTY: (.4 * rng.random(n), np.full(n, .5))}[tgt]
+    fields = [(hip.F_MOD_FREQUENCY, mod_freq), (hip.F_MOD_SCALE, scale), (hip.F_MOD_OFFSET, offset),
+              (hip.F_MOD_WAVE, mod_wave)]
 
     def run():
-        bank = hip_bank_from_patch(hip, ctx, patch, mod_target=hip.MOD_FM)
+        bank = hip_bank_from_patch(hip, ctx, patch, mod_target=tgt)
         for field, values in fields:
             bank.set(field, values)
         voices = bank.render_voices(nb, f64=True)
@@ -96,9 +112,10 @@ def test_fm_fast_form_vs_general_kernel(hip, ctx, monkeypatch, seed):
     fast = run()
     monkeypatch.setenv('KLMI_FM_KERNEL', '0')
     general = run()
-    # sine carriers: the exact form calls sin() outside [0, TAU], the speculative one the
-    # wrapped polynomial -- both within an ulp of the true value
-    if (np.asarray(patch['wave']) == 0).any():
+    sines = (np.asarray(patch['wave']) == 0).any() or (np.asarray(mod_wave) == 0).any()
+    if tgt == hip.MOD_FM and sines:
+        # sine carriers: the exact form calls sin() outside [0, TAU], the speculative one the
+        # wrapped polynomial -- both within an ulp of the true value
         assert np.abs(fast[0] - general[0]).max() <= 1e-13
         for x, y in zip(fast[2], general[2]):
             np.testing.assert_allclose(x, y, rtol=0, atol=1e-12)

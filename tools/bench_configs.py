@@ -4,7 +4,7 @@ not bench.py's headline: config 2 (haunting patch, replicated), config 3 in
 materialised mode (per-voice float32 streams written to HBM) and config 4
 (reverb channels, delay lines in HBM).  Usage:
 
-    python tools/bench_configs.py [2] [3m] [3fm] [3fx] [3delay] [synth] [4] [4big]
+    python tools/bench_configs.py [2] [3m] [3fm] [3vib] [3pwm] [3fx] [3delay] [synth] [4] [4big]
 """
 import json
 import os
@@ -103,10 +103,22 @@ def config3_general(ctx, label, **bank_kw):
     p['events'] = ev[:0]
     bank.load_patch(p)
     rng = np.random.default_rng(9)
-    if bank_kw.get('mod_target'):
+    target = bank_kw.get('mod_target')
+    if target == native.MOD_FM:
         bank.set(native.F_MOD_FREQUENCY, 20. + 200. * rng.random(n))
         bank.set(native.F_MOD_SCALE, 2. * rng.random(n))
         bank.set(native.F_MOD_WAVE, np.full(n, native.WAVE_SAWTOOTH))
+    elif target == native.MOD_FREQUENCY:      # vibrato: +-2 % around the voice's pitch, 3-8 Hz
+        bank.set(native.F_MOD_FREQUENCY, 3. + 5. * rng.random(n))
+        bank.set(native.F_MOD_SCALE, .02 * np.asarray(patch.frequency))
+        bank.set(native.F_MOD_OFFSET, np.asarray(patch.frequency, dtype=float))
+        bank.set(native.F_MOD_WAVE, np.full(n, native.WAVE_SINE))
+    elif target == native.MOD_DUTY:           # pulse width swept between .1 and .9
+        bank.set(native.F_WAVE, np.full(n, native.WAVE_PWM))
+        bank.set(native.F_MOD_FREQUENCY, .5 + 4. * rng.random(n))
+        bank.set(native.F_MOD_SCALE, np.full(n, .4))
+        bank.set(native.F_MOD_OFFSET, np.full(n, .5))
+        bank.set(native.F_MOD_WAVE, np.full(n, native.WAVE_TRIANGLE))
     for s, kind in enumerate(bank_kw.get('effects', ())):
         if kind == native.FX_TREMOLO:
             bank.set(native.F_FX(s, 0), 1. + 8. * rng.random(n))
@@ -120,7 +132,7 @@ def config3_general(ctx, label, **bank_kw):
     units = n * n_blocks * B
     kernel = ('general kernel (KLMI_FM_KERNEL / KLMI_FX_KERNEL = 0)'
               if '0' in (os.environ.get('KLMI_FM_KERNEL'), os.environ.get('KLMI_FX_KERNEL'))
-              else 'FM form of the fast kernel' if bank_kw.get('mod_target') else 'compiled stage program')
+              else 'modulated form of the fast kernel' if bank_kw.get('mod_target') else 'compiled stage program')
     return dict(config='3 with %s, %s: 65,536 voices x %d blocks' % (label, kernel, n_blocks),
                 value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
                 launches=launches)
@@ -200,6 +212,11 @@ def main():
             r = config4(ctx)
         elif w == '3fm':
             r = config3_general(ctx, 'FmOscillator (saw modulator)', mod_target=native.MOD_FM)
+        elif w == '3vib':
+            r = config3_general(ctx, 'Lfo(256, sine) -> Oscillator.frequency', mod_target=native.MOD_FREQUENCY)
+        elif w == '3pwm':
+            r = config3_general(ctx, 'Lfo(256, triangle) -> PwmOscillator.dutyCycle',
+                                mod_target=native.MOD_DUTY)
         elif w == '3fx':
             r = config3_general(ctx, 'Filter -> Tremolo -> Gain',
                                 effects=[native.FX_FILTER, native.FX_TREMOLO, native.FX_GAIN])
