@@ -207,7 +207,7 @@ def main():
         from klang_amd import sharding
         dist.init_process_group('gloo')
 
-        def reduce_via_host(bus, n_total, world_size, dst=0, group=None):
+        def reduce_via_host(bus, n_total, world_size, dst=0, group=None, always=False):
             host = bus.cpu()
             dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
             bus.copy_(host)
