@@ -95,7 +95,7 @@ def config3_materialised(ctx):
 def config3_general(ctx, label, **bank_kw):
     """Config 3's patch through the general kernel (mod_kernels.h): with an FmOscillator
     per voice, or with effect stages around the Filter."""
-    n, n_blocks = 65536, 128
+    n, n_blocks = int(os.environ.get('KLANG_CONFIG3_VOICES', 65536)), 128
     patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=n_blocks, off_base=20, off_span=40)
     bank = native.Bank(ctx, n, has_env=True, has_filter=True, **bank_kw)
     ev = patch.events
@@ -133,7 +133,7 @@ def config3_general(ctx, label, **bank_kw):
     kernel = ('general kernel (KLMI_FM_KERNEL / KLMI_FX_KERNEL = 0)'
               if '0' in (os.environ.get('KLMI_FM_KERNEL'), os.environ.get('KLMI_FX_KERNEL'))
               else 'modulated form of the fast kernel' if bank_kw.get('mod_target') else 'compiled stage program')
-    return dict(config='3 with %s, %s: 65,536 voices x %d blocks' % (label, kernel, n_blocks),
+    return dict(config='3 with %s, %s: %s voices x %d blocks' % (label, kernel, format(n, ','), n_blocks),
                 value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
                 launches=launches)
 
