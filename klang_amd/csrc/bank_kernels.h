@@ -283,8 +283,13 @@ __device__ __forceinline__ void lfo_cutoff_step(const BankView &bk, int v, doubl
 // region of their own in front of the straight-line region (independent samples, the wave
 // function chosen by one scalar jump, the remainder repaired in place); the running frequency
 // sum is one more serial recurrence -- a single add per sample -- beside envelope and biquad.
-template <bool ENV, bool FILT, int MODE, bool GATED = false, int MOD = MT_NONE>
-__global__ __launch_bounds__(kGroup) void voice_kernel(BankView bk, int first, int count,
+// OCC: waves per SIMD the register budget allows.  2 (256 registers per lane) lets banks above
+// 65,536 voices run two workgroups per compute unit side by side (131,072 voices: 1.01e12 ->
+// 1.24e12 voice-samples/s); with ONE workgroup per compute unit the unconstrained allocation
+// (256 + 18 registers) is 2 % faster, so plain chains are also built with OCC = 1
+// (voice1_tu.hip) for grids that do not exceed the compute units.
+template <bool ENV, bool FILT, int MODE, bool GATED = false, int MOD = MT_NONE, int OCC = 2>
+__global__ __launch_bounds__(kGroup, OCC) void voice_kernel(BankView bk, int first, int count,
                                                        int block_base,      // first block, relative to this call
                                                        uint32_t clock_base,  // absolute number of block_base (events)
                                                        int n_blocks,

@@ -276,6 +276,8 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
     if (e == hipSuccess)
         e = upload_time_table_voice(t);
     if (e == hipSuccess)
+        e = upload_time_table_voice1(t);
+    if (e == hipSuccess)
         e = upload_time_table_mod(t);
     if (e == hipSuccess)
         e = upload_time_table_fm(t);
@@ -1522,6 +1524,11 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
     if (view.mod_target != MT_NONE || !plain_chain || (view.gated && !fast_gated))
         return launch_mod_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                  n_blocks, span_total, partial, out);
+    // one workgroup per compute unit at most: the build without the two-waves register cap
+    const char *waves_knob = getenv("KLMI_VOICE_WAVES");   // tuning knob: 2 = always the capped build
+    if (!view.gated && (count + kGroup - 1) / kGroup <= n_cus && !(waves_knob && waves_knob[0] == '2'))
+        return launch_voice_kernel_one_wave(env, filt, MODE, st, view, first, count, block_base,
+                                            clock_base, n_blocks, span_total, partial, out);
     return launch_voice_kernel(env, filt, view.gated != 0, MODE, st, view, first, count, block_base,
                                clock_base, n_blocks, span_total, partial, out);
 }

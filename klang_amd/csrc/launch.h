@@ -29,6 +29,7 @@ inline hipError_t allow_dynamic_lds(const void *kernel, size_t bytes, std::atomi
 
 // t[n] = DT * n into the unit's own constant table (kTimeSlots doubles)
 hipError_t upload_time_table_voice(const double *t);
+hipError_t upload_time_table_voice1(const double *t);
 hipError_t upload_time_table_mod(const double *t);
 hipError_t upload_time_table_fm(const double *t);
 hipError_t upload_time_table_fx(const double *t);
@@ -37,6 +38,12 @@ hipError_t upload_time_table_fx(const double *t);
 hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStream_t st,
                                const BankView &view, int first, int count, int block_base, uint32_t clock_base,
                                int n_blocks, int span_total, float *partial, void *out);
+// the same for plain ungated chains, built for one wave per SIMD (voice1_tu.hip): grids of at
+// most one workgroup per compute unit
+hipError_t launch_voice_kernel_one_wave(bool env, bool filt, int mode, hipStream_t st,
+                                        const BankView &view, int first, int count, int block_base,
+                                        uint32_t clock_base, int n_blocks, int span_total,
+                                        float *partial, void *out);
 // voice_kernel<..., MOD> (fm_tu.hip): voices with an audio-rate modulation input (FmOscillator,
 // Lfo -> frequency, Lfo -> duty cycle), ungated, plain [Filter] chain; mod_fast_form says
 // whether the bank and output mode have an instantiation

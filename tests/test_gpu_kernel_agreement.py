@@ -68,6 +68,9 @@ def test_plain_chains_lane_per_voice_vs_pipelined(hip, ctx, monkeypatch, seed):
     split = int(rng.integers(1, nb))
     monkeypatch.setenv('KLMI_PIPE_VOICES_LOG2', '-1')
     want = outcome(hip, ctx, patch, nb, split)
+    monkeypatch.setenv('KLMI_VOICE_WAVES', '2')    # the build for two waves per SIMD (large banks)
+    assert_same(outcome(hip, ctx, patch, nb, split), want)
+    monkeypatch.delenv('KLMI_VOICE_WAVES')
     for log2 in ('0', '2', '5', '6'):
         monkeypatch.setenv('KLMI_PIPE_VOICES_LOG2', log2)
         assert_same(outcome(hip, ctx, patch, nb, split), want)
