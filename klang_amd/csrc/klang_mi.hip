@@ -1594,7 +1594,13 @@ static int render_mix(klmi_bank *b, int n_blocks, float *dev_mix, unsigned char 
     float *partial;
     double *stage;
     if (may_alloc) {
-        bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, ((size_t)256 << 20) / per_block));
+        size_t cap_mib = 256;
+        if (const char *e = getenv("KLMI_PARTIAL_MIB")) {   // tuning knob: partial-bus bytes per launch
+            const long v = atol(e);
+            if (v >= 1 && v <= 8192)
+                cap_mib = (size_t)v;
+        }
+        bpl = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_blocks, (cap_mib << 20) / per_block));
         HIP_TRY(b->partial.reserve((size_t)rows * planes * kBlock * bpl));
         HIP_TRY(b->stage.reserve((size_t)slices * planes * kBlock * bpl));
         partial = b->partial.p;
