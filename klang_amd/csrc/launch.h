@@ -1,7 +1,9 @@
-// launch.h -- host-side entry points of the two big kernel families.  Each family is a
-// translation unit of its own (voice_tu.hip: voice_kernel<ENV,FILT,MODE>, mod_tu.hip:
-// voice_mod_kernel<MODE>) so that the library builds in parallel and an edit to the host
-// code does not recompile them.
+// launch.h -- host-side entry points of the voice kernel families.  Each family is a
+// translation unit of its own -- voice_tu.hip / voice1_tu.hip: voice_kernel in its two
+// register budgets; fm_tu.hip (three objects): its modulated forms; fx_tu.hip: voice_fx_kernel;
+// mod_tu.hip: voice_mod_kernel; pipe_tu.hip: voice_pipe_kernel -- so that the library builds
+// in parallel and an edit to the host code does not recompile them.  Each object holds its
+// own copy of the constant time table (upload_time_table_*).
 #pragma once
 #include "bank_kernels.h"
 
