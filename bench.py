@@ -168,6 +168,93 @@ def cpu_baseline(n_voices, log):
     }
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, script=None, env=None, timeout=None, out=sys.stdout, err=sys.stderr):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes
+    (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the same
+    variables torch.distributed.run would set), wait for all of them, relay rank 0's stdout
+    (the ONE JSON line) and return a non-zero code if any rank failed.  The parent never
+    touches the GPU or imports torch: nothing that has initialised HIP is re-executed.
+    A rank that dies takes the others down (they would wait in the rendezvous forever)."""
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                MASTER_PORT=str(free_port()))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, '-u', script] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None if err is sys.stderr else subprocess.PIPE,
+                                      text=True))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    codes = [None] * n
+    rank0_out = None
+    try:
+        while any(c is None for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None and p.poll() is not None:
+                    codes[r] = p.returncode
+                    if r == 0:
+                        rank0_out = p.stdout.read()
+            if any(c not in (None, 0) for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                break
+            time.sleep(.05)
+    finally:
+        for r, p in enumerate(procs):           # exact PIDs we started, nothing by pattern
+            if p.poll() is None:
+                p.terminate()
+        for r, p in enumerate(procs):
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+            if codes[r] is None:
+                codes[r] = p.returncode if p.returncode is not None else -9
+        if rank0_out is None and procs[0].stdout is not None:
+            try:
+                rank0_out = procs[0].stdout.read()
+            except (OSError, ValueError):
+                rank0_out = ''
+    if err is not sys.stderr:
+        for r, p in enumerate(procs):
+            if p.stderr is not None:
+                err.write(p.stderr.read())
+    failed = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if failed:
+        print('[bench] ranks failed (rank, exit code): %s' % failed, file=sys.stderr, flush=True)
+        return 1
+    # libraries may chat on stdout (gloo does); the record is the line that is a JSON object
+    lines = []
+    for ln in (rank0_out or '').splitlines():
+        if ln.lstrip().startswith('{'):
+            try:
+                json.loads(ln)
+                lines.append(ln.strip())
+            except ValueError:
+                pass
+        elif ln.strip():
+            print('[rank 0 stdout] ' + ln, file=sys.stderr, flush=True)
+    if len(lines) != 1:
+        print('[bench] rank 0 printed %d JSON lines, expected ONE' % len(lines),
+              file=sys.stderr, flush=True)
+        return 1
+    out.write(lines[0] + '\n')
+    out.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -180,10 +267,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if args.gpus > 1 and world == 1:
-        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N ...')
+        # no launcher: this process becomes the launcher (before any torch / GPU call)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     def log(msg):
         if rank == 0:
@@ -222,31 +310,8 @@ def main():
     VOICES_PER_GPU = int(os.environ.get('KLANG_BENCH_VOICES',
                                         VOICES_SINGLE if world == 1 else VOICES_SHARD))
     n_total = VOICES_PER_GPU * world
-    steps_total = args.warmup + args.steps
     stream = torch.cuda.current_stream()
     ctx = native.Context(local_rank, stream.cuda_stream)
-    patch = patches.polyphonic_saw_patch(n_voices=n_total, n_blocks=BLOCKS_PER_STEP,
-                                         first_voice=rank * VOICES_PER_GPU, count=VOICES_PER_GPU)
-    bank = native.Bank(ctx, patch.n_voices, has_env=True, has_filter=True)
-    events = patch.events
-    patch_no_events = patches.Patch(patch)
-    patch_no_events['events'] = events[:0]
-    bank.load_patch(patch_no_events)
-    # pre-upload the events of every step (re-triggered patch), block numbers absolute
-    all_events = []
-    for s in range(steps_total):
-        ev = events.copy()
-        ev['block'] += s * BLOCKS_PER_STEP
-        all_events.append(ev)
-    bank.events(np.concatenate(all_events))
-
-    mixer = ShardedMixer(bank, n_total, BLOCKS_PER_STEP, world, rank)
-    host_bus = torch.empty((BLOCKS_PER_STEP, 1, B), dtype=torch.float32).pin_memory()
-
-    def step():
-        bus = mixer.render()            # voice kernel(s) + bus reduce (+ RCCL reduce)
-        if rank == 0:
-            host_bus.copy_(bus, non_blocking=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -254,29 +319,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms, step_ms, launches = [], [], 0
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        step()
-        # HIP-event durations of this step's voice-kernel launches (same stream);
-        # reading them waits for the step, which the next step depends on anyway
-        ms, launches = bank.last_kernel_ms()
-        kernel_ms.append(ms)
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def run_steps(n_total, voices_per_gpu, warmup, steps):
+        """W untimed + exactly K timed steps of the sharded patch; returns the max-over-ranks
+        wall time of the K steps and the per-step HIP-event kernel times of this rank."""
+        steps_total = warmup + steps
+        patch = patches.polyphonic_saw_patch(n_voices=n_total, n_blocks=BLOCKS_PER_STEP,
+                                             first_voice=rank * voices_per_gpu, count=voices_per_gpu)
+        bank = native.Bank(ctx, patch.n_voices, has_env=True, has_filter=True)
+        events = patch.events
+        patch_no_events = patches.Patch(patch)
+        patch_no_events['events'] = events[:0]
+        bank.load_patch(patch_no_events)
+        # pre-upload the events of every step (re-triggered patch), block numbers absolute
+        all_events = []
+        for s in range(steps_total):
+            ev = events.copy()
+            ev['block'] += s * BLOCKS_PER_STEP
+            all_events.append(ev)
+        bank.events(np.concatenate(all_events))
+
+        mixer = ShardedMixer(bank, n_total, BLOCKS_PER_STEP, world, rank)
+        host_bus = torch.empty((BLOCKS_PER_STEP, 1, B), dtype=torch.float32).pin_memory()
+
+        def step():
+            bus = mixer.render()            # voice kernel(s) + bus reduce (+ RCCL reduce)
+            if rank == 0:
+                host_bus.copy_(bus, non_blocking=True)
+
+        kernel_ms, step_ms, launches = [], [], 0
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ts = time.perf_counter()
+            step()
+            # HIP-event durations of this step's voice-kernel launches (same stream);
+            # reading them waits for the step, which the next step depends on anyway
+            ms, launches = bank.last_kernel_ms()
+            kernel_ms.append(ms)
+            step_ms.append((time.perf_counter() - ts) * 1e3)
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        if rank == 0:
+            peak = float(host_bus.abs().max())
+            assert np.isfinite(peak) and peak > 1e-4, \
+                'mix bus is silent or not finite (peak %r)' % peak
+        fence()
+        bank.close()
+        return elapsed, kernel_ms, step_ms, launches
+
+    elapsed, kernel_ms, step_ms, launches = run_steps(n_total, VOICES_PER_GPU, args.warmup,
+                                                      args.steps)
 
     if rank == 0:
-        peak = float(host_bus.abs().max())
-        assert np.isfinite(peak) and peak > 1e-4, 'mix bus is silent or not finite (peak %r)' % peak
         units = n_total * BLOCKS_PER_STEP * B * args.steps
         value = units / elapsed
         per_launch_units = VOICES_PER_GPU * BLOCKS_PER_STEP * B / max(launches, 1)
@@ -315,6 +415,7 @@ def main():
                 'parallelism': 'voice shards x%d, one RCCL reduce of the mix bus per step' % world
                                if world > 1 else 'single GPU',
             },
+            'per_gpu_value': value / world,
             'realtime_voices': value / 44100.,
             'roofline': {
                 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -336,12 +437,27 @@ def main():
         }
         if world == 1 and not args.no_extra:
             result['extra'] = extra_records(ctx, native, patches, torch, log)
+            if VOICES_PER_GPU != VOICES_SHARD:
+                # the N = 1 point on the per-GPU workload of N > 1 (131,072 voices per GPU): the
+                # same step, timed the same way, so that the N > 1 lines have a like-for-like base
+                e2, k2, s2, l2 = run_steps(VOICES_SHARD, VOICES_SHARD, args.warmup, args.steps)
+                v2 = VOICES_SHARD * BLOCKS_PER_STEP * B * args.steps / e2
+                result['extra']['shard_131072'] = {
+                    'workload': 'the same step on the per-GPU shard size of --gpus N > 1: 131,072 '
+                                'voices on this one GPU (two waves per SIMD instead of one)',
+                    'value': v2, 'unit': 'voice-samples/s', 'ms_per_step': e2 / args.steps * 1e3,
+                    'ms_per_step_spread': stats(s2), 'steps': args.steps, 'warmup': args.warmup,
+                    'launch_ms_spread': stats([k / max(l2, 1) for k in k2]),
+                    'launches_per_step': l2,
+                    'note': 'weak-scaling efficiency at N GPUs like for like = per_gpu_value(N) / '
+                            'this value; the headline N = 1 line is BASELINE configs[2] (65,536 '
+                            'voices, one wave per SIMD)'}
+                log('shard_131072: %.4g voice-samples/s' % v2)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(VOICES_PER_GPU, log)
         print(json.dumps(result), flush=True)
 
     fence()
-    bank.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
