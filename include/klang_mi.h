@@ -389,6 +389,15 @@ int klmi_bank_bounce(klmi_bank *bank, double duration, double fadeout, float *ho
                      int16_t *host_pcm, float *host_peak);
 int klmi_bank_bounce_device(klmi_bank *bank, double duration, double fadeout, float *dev_frames,
                             int16_t *dev_pcm, float *dev_peak);
+/* The output side alone, for a bus rendered elsewhere: one process per GPU renders its
+ * voice shard with klmi_bank_render_device (mix divisor 1), ONE reduce sums the partial
+ * buses over the ranks (klang/audio/mixer.py:41-49 is the only cross-voice operation; the
+ * root divides by the global input count, :46-47), and the root hands the summed bus
+ * dev_bus [nCycles][channels][256] float32 to this call for Dac packing, fade-out and the
+ * peak-normalised int16 samples exactly as above (klanggeber.py:81-97, 205-249,
+ * wavfile.py:54-63).  Renders nothing; the bank's state, events and block clock stay. */
+int klmi_bank_bounce_bus(klmi_bank *bank, const float *dev_bus, double duration, double fadeout,
+                         float *host_frames, int16_t *host_pcm, float *host_peak);
 
 /* Reverb delay-line state of one voice: rings concatenated in tap order
  * (sum of tap lengths float64) and the ring positions [n_echos]. */

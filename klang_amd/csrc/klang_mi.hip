@@ -905,12 +905,16 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         if (rc == 0)
             rc = r;
     };
-    if (hipMemset(b->state_f64.p, 0, sizeof(double) * b->f64_slots * n) != hipSuccess ||
-        hipMemset(b->state_u32.p, 0, sizeof(uint32_t) * SL_U32_COUNT * n) != hipSuccess ||
-        hipMemset(b->ev_offset.p, 0, sizeof(uint32_t) * (n + 1)) != hipSuccess ||
-        hipMemset(b->wave.p, 0, sizeof(int32_t) * n) != hipSuccess ||
+    // cleared ON THE CONTEXT'S STREAM, like every launch: a caller's non-blocking stream is not
+    // ordered with the null stream, so a null-stream hipMemset could still be running (or
+    // run late) when the first render reads the state
+    hipStream_t cst = ctx->stream;
+    if (hipMemsetAsync(b->state_f64.p, 0, sizeof(double) * b->f64_slots * n, cst) != hipSuccess ||
+        hipMemsetAsync(b->state_u32.p, 0, sizeof(uint32_t) * SL_U32_COUNT * n, cst) != hipSuccess ||
+        hipMemsetAsync(b->ev_offset.p, 0, sizeof(uint32_t) * (n + 1), cst) != hipSuccess ||
+        hipMemsetAsync(b->wave.p, 0, sizeof(int32_t) * n, cst) != hipSuccess ||
         (desc->poly_voices > 0 &&
-         hipMemset(b->nt_offset.p, 0, sizeof(uint32_t) * (n / desc->poly_voices + 1)) != hipSuccess))
+         hipMemsetAsync(b->nt_offset.p, 0, sizeof(uint32_t) * (n / desc->poly_voices + 1), cst) != hipSuccess))
         step(fail(KLMI_E_DEVICE, "klmi_bank_create: memset failed"));
     step(fill_device<double>(b, b->duty.p, n, .5));           // oscillators.py:245
     step(fill_device<double>(b, b->f64(SL_FREQ), n, 440.));   // oscillators.py:121
@@ -1826,17 +1830,14 @@ extern "C" int klmi_bounce_cycles(double duration)
     return q > 2147483647. ? 2147483647 : (int)q;
 }
 
-// frames / pcm / peak on the device; dev_frames may be the bank's own staging buffer
-static int bounce_device(klmi_bank *b, int n_blocks, double duration, double fadeout,
-                         float *dev_frames, int16_t *dev_pcm, float *dev_peak)
+// The output side alone: `bus` [n_blocks][ch][256] float32 (mixed, on the device) -> frames /
+// pcm / peak.  dev_frames may be the bank's own staging buffer.
+static int bounce_finish(klmi_bank *b, const float *bus, int n_blocks, double duration,
+                         double fadeout, float *dev_frames, int16_t *dev_pcm, float *dev_peak)
 {
     hipStream_t st = b->ctx->stream;
     const int ch = b->desc.stereo ? 2 : 1;
     const size_t len = (size_t)n_blocks * ch * kBlock;
-    HIP_TRY(b->dev_mix.reserve(len));
-    b->last_mix_blocks = 0;
-    TRY(render_mix(b, n_blocks, b->dev_mix.p));
-    b->last_mix_blocks = n_blocks;
     // playTime += INTERVAL, a running float64 sum (klanggeber.py:199, 248)
     std::vector<double> play_time(n_blocks);
     double t = 0.;
@@ -1851,10 +1852,10 @@ static int bounce_device(klmi_bank *b, int n_blocks, double duration, double fad
     HIP_TRY(hipStreamSynchronize(st));  // play_time dies here
     const double fade_start = duration - fadeout;
     if (ch == 2)
-        hipLaunchKernelGGL(bounce_pack_kernel<2>, dim3(n_blocks), dim3(kBlock), 0, st, b->dev_mix.p,
+        hipLaunchKernelGGL(bounce_pack_kernel<2>, dim3(n_blocks), dim3(kBlock), 0, st, bus,
                            b->bounce_time.p, fade_start, duration, dev_frames, b->bounce_peak.p);
     else
-        hipLaunchKernelGGL(bounce_pack_kernel<1>, dim3(n_blocks), dim3(kBlock), 0, st, b->dev_mix.p,
+        hipLaunchKernelGGL(bounce_pack_kernel<1>, dim3(n_blocks), dim3(kBlock), 0, st, bus,
                            b->bounce_time.p, fade_start, duration, dev_frames, b->bounce_peak.p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(bounce_peak_kernel, dim3(1), dim3(256), 0, st, b->bounce_peak.p, n_blocks,
@@ -1867,6 +1868,19 @@ static int bounce_device(klmi_bank *b, int n_blocks, double duration, double fad
         HIP_TRY(hipGetLastError());
     }
     return 0;
+}
+
+// render + output side; dev_frames may be the bank's own staging buffer
+static int bounce_device(klmi_bank *b, int n_blocks, double duration, double fadeout,
+                         float *dev_frames, int16_t *dev_pcm, float *dev_peak)
+{
+    const int ch = b->desc.stereo ? 2 : 1;
+    const size_t len = (size_t)n_blocks * ch * kBlock;
+    HIP_TRY(b->dev_mix.reserve(len));
+    b->last_mix_blocks = 0;
+    TRY(render_mix(b, n_blocks, b->dev_mix.p));
+    b->last_mix_blocks = n_blocks;
+    return bounce_finish(b, b->dev_mix.p, n_blocks, duration, fadeout, dev_frames, dev_pcm, dev_peak);
 }
 
 static int bounce_args(klmi_bank *b, double duration, double fadeout, int *n_blocks)
@@ -1898,20 +1912,11 @@ extern "C" int klmi_bank_bounce_device(klmi_bank *b, double duration, double fad
     return bounce_device(b, n_blocks, duration, fadeout, dev_frames, dev_pcm, dev_peak);
 }
 
-extern "C" int klmi_bank_bounce(klmi_bank *b, double duration, double fadeout, float *host_frames,
-                                int16_t *host_pcm, float *host_peak)
+// frames / pcm / peak to the host after bounce_device / bounce_finish wrote them
+static int bounce_download(klmi_bank *b, size_t len, const float *dev_peak, float *host_frames,
+                           int16_t *host_pcm, float *host_peak)
 {
-    int n_blocks = 0;
-    TRY(bounce_args(b, duration, fadeout, &n_blocks));
-    TRY(use(b->ctx));
     hipStream_t st = b->ctx->stream;
-    const size_t len = (size_t)n_blocks * (b->desc.stereo ? 2 : 1) * kBlock;
-    HIP_TRY(b->bounce_frames.reserve(len + 4));  // + the peak, behind the frames
-    float *dev_peak = b->bounce_frames.p + len;
-    if (host_pcm)
-        HIP_TRY(b->bounce_pcm.reserve(len));
-    TRY(bounce_device(b, n_blocks, duration, fadeout, b->bounce_frames.p,
-                      host_pcm ? b->bounce_pcm.p : nullptr, dev_peak));
     float peak = 0.f;
     HIP_TRY(hipMemcpyAsync(&peak, dev_peak, sizeof(float), hipMemcpyDeviceToHost, st));
     if (host_frames)
@@ -1926,6 +1931,45 @@ extern "C" int klmi_bank_bounce(klmi_bank *b, double duration, double fadeout, f
     if (host_pcm && peak == 0.f)
         return fail(KLMI_E_ARG, "Zero amplitude! Can not normalize!");  // math.py:17-19
     return 0;
+}
+
+extern "C" int klmi_bank_bounce(klmi_bank *b, double duration, double fadeout, float *host_frames,
+                                int16_t *host_pcm, float *host_peak)
+{
+    int n_blocks = 0;
+    TRY(bounce_args(b, duration, fadeout, &n_blocks));
+    TRY(use(b->ctx));
+    const size_t len = (size_t)n_blocks * (b->desc.stereo ? 2 : 1) * kBlock;
+    HIP_TRY(b->bounce_frames.reserve(len + 4));  // + the peak, behind the frames
+    float *dev_peak = b->bounce_frames.p + len;
+    if (host_pcm)
+        HIP_TRY(b->bounce_pcm.reserve(len));
+    TRY(bounce_device(b, n_blocks, duration, fadeout, b->bounce_frames.p,
+                      host_pcm ? b->bounce_pcm.p : nullptr, dev_peak));
+    return bounce_download(b, len, dev_peak, host_frames, host_pcm, host_peak);
+}
+
+// The output side of a bounce for a bus that was rendered elsewhere: klmi_bank_render_device
+// on every GPU of a sharded patch, the partial buses summed over the ranks (one RCCL reduce)
+// and divided by the global input count -- the root then packs / fades / normalises HERE.
+// Nothing is rendered and the bank's state does not move.
+extern "C" int klmi_bank_bounce_bus(klmi_bank *b, const float *dev_bus, double duration,
+                                    double fadeout, float *host_frames, int16_t *host_pcm,
+                                    float *host_peak)
+{
+    int n_blocks = 0;
+    TRY(bounce_args(b, duration, fadeout, &n_blocks));
+    if (!dev_bus)
+        return fail(KLMI_E_ARG, "klmi_bank_bounce_bus: null bus");
+    TRY(use(b->ctx));
+    const size_t len = (size_t)n_blocks * (b->desc.stereo ? 2 : 1) * kBlock;
+    HIP_TRY(b->bounce_frames.reserve(len + 4));
+    float *dev_peak = b->bounce_frames.p + len;
+    if (host_pcm)
+        HIP_TRY(b->bounce_pcm.reserve(len));
+    TRY(bounce_finish(b, dev_bus, n_blocks, duration, fadeout, b->bounce_frames.p,
+                      host_pcm ? b->bounce_pcm.p : nullptr, dev_peak));
+    return bounce_download(b, len, dev_peak, host_frames, host_pcm, host_peak);
 }
 
 extern "C" int klmi_bank_last_kernel_ms(klmi_bank *b, float *voice_ms, int *launches)
@@ -2234,8 +2278,8 @@ extern "C" int klmi_env_create(klmi_ctx *ctx, int count, double attack, double d
     if (err == hipSuccess) err = e->value.alloc(count);
     if (err == hipSuccess) err = e->flags.alloc(count);
     if (err == hipSuccess) err = e->state.alloc(count);
-    if (err == hipSuccess) err = hipMemset(e->value.p, 0, sizeof(double) * count);
-    if (err == hipSuccess) err = hipMemset(e->state.p, 0, sizeof(uint32_t) * count);
+    if (err == hipSuccess) err = hipMemsetAsync(e->value.p, 0, sizeof(double) * count, ctx->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(e->state.p, 0, sizeof(uint32_t) * count, ctx->stream);
     if (err != hipSuccess) {
         delete e;
         return fail(KLMI_E_MEMORY, "klmi_env_create: %s", hipGetErrorString(err));
@@ -2430,7 +2474,8 @@ extern "C" int klmi_comb_create(klmi_ctx *ctx, int kind, int count, int length, 
     c->length = length;
     hipError_t e = c->alpha.alloc(count);
     if (e == hipSuccess) e = c->ring.alloc((size_t)length * count);
-    if (e == hipSuccess) e = hipMemset(c->ring.p, 0, sizeof(double) * (size_t)length * count);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(c->ring.p, 0, sizeof(double) * (size_t)length * count, ctx->stream);
     if (e == hipSuccess) {
         std::vector<double> a(count, alpha);
         e = hipMemcpy(c->alpha.p, a.data(), sizeof(double) * count, hipMemcpyHostToDevice);
@@ -2534,8 +2579,9 @@ extern "C" int klmi_kick_create(klmi_ctx *ctx, int count, klmi_kick **out)
     if (e == hipSuccess) e = k->time.alloc(count);
     if (e == hipSuccess) e = k->phase.alloc((size_t)count * kBlock);
     if (e == hipSuccess) e = k->t_table.alloc(kBlock);
-    if (e == hipSuccess) e = hipMemset(k->time.p, 0, sizeof(double) * count);
-    if (e == hipSuccess) e = hipMemset(k->phase.p, 0, sizeof(double) * count * kBlock);
+    if (e == hipSuccess) e = hipMemsetAsync(k->time.p, 0, sizeof(double) * count, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(k->phase.p, 0, sizeof(double) * count * kBlock, ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpy(k->par.p, par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess)

@@ -91,6 +91,7 @@ class Chain:
         self.modulator = None           # Lfo(shape=256) or FmOscillator.modulator
         self.external = external        # the Output whose samples feed the first stage, when the
                                         # source is not a device oscillator
+        self.patched_params = False     # some stage parameter input is connected (block rate)
         if end is not None:
             self._walk(end)
 
@@ -119,6 +120,7 @@ class Chain:
                     raise NotFusable('%s: a parameter input carries an array per buffer '
                                      '(audio-rate modulation of effect parameters is not fused)'
                                      % stage)
+                self.patched_params = True
         if kind is RingModulator:
             if stage.lfo.wave_func not in WAVE_IDS or WAVE_IDS[stage.lfo.wave_func] > native.WAVE_TRIANGLE:
                 raise NotFusable('%s: Lfo wave function %r has no device twin'
@@ -289,6 +291,10 @@ class GpuVoiceBank(Block):
                                 # to device and both banks render ahead in lock-step
         self._fresh = 0         # buffers of the last render() a downstream bank may still take
         self._twins = []        # banks for channels 1.. of a chain fed with a multi-channel signal
+        # A connected stage parameter (host Lfo -> Gain.gain ...) changes every buffer in the
+        # reference, and its value is only read when a render is prepared: such a bank renders
+        # ONE buffer per call whatever lookahead the caller asks for (like a host-fed bank).
+        self.patched_params = any(c.patched_params for c in chains)
         self.lookahead = 1      # blocks rendered per device call (set by run_klang)
         self.remaining = None   # buffers still to be delivered, when the caller knows (offline
                                 # bounce): rendering ahead never runs past the end of the piece
@@ -456,7 +462,8 @@ class GpuVoiceBank(Block):
             self._collect_events()
             chained = self.upstream is not None and self.upstream._fresh > 0
             # float32 [n][channels][256] -> per buffer (256,) mono or (2, 256) stereo
-            ahead = 1 if (self.external and not chained) else max(1, int(self.lookahead))
+            ahead = (1 if (self.external and not chained) or self.patched_params
+                     else max(1, int(self.lookahead)))
             if self.remaining is not None:
                 ahead = max(1, min(ahead, int(self.remaining)))
             if chained:

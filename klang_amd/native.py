@@ -469,6 +469,20 @@ class Bank:
                                        C.byref(peak)))
         return frames, pcm, peak.value
 
+    def bounce_bus(self, bus_ptr, duration, fadeout=0., want_pcm=True):
+        """The output side of bounce() for a device bus [cycles][channels][256] float32 that was
+        rendered and summed elsewhere (klmi_bank_bounce_bus) -> (frames, pcm or None, peak)."""
+        cycles = load().klmi_bounce_cycles(float(duration)) if np.isfinite(duration) else 0
+        shape = (max(cycles, 0) * BUFFER_SIZE, self.channels)
+        frames = np.empty(shape, dtype=np.float32)
+        pcm = np.empty(shape, dtype=np.int16) if want_pcm else None
+        peak = C.c_float(0.)
+        _check(load().klmi_bank_bounce_bus(self._h, _vp(bus_ptr), float(duration), float(fadeout),
+                                           frames.ctypes.data_as(_vp),
+                                           pcm.ctypes.data_as(_vp) if want_pcm else None,
+                                           C.byref(peak)))
+        return frames, pcm, peak.value
+
     def bounce_device(self, duration, fadeout, frames_ptr, pcm_ptr, peak_ptr):
         _check(load().klmi_bank_bounce_device(self._h, float(duration), float(fadeout),
                                               frames_ptr, pcm_ptr, peak_ptr))

@@ -350,6 +350,33 @@ def test_block_rate_patched_parameters_vs_reference_fixture(hip, golden):
     assert report('effect parameters patched at block rate', np.abs(got[:, 0] - want.ravel()).max()) <= 1e-5
 
 
+def test_patched_parameters_ignore_an_explicit_lookahead(hip, golden):
+    """run_klang(lookahead=8) on a patch whose effect parameters are patched at block rate: the
+    reference changes the value every buffer, so the bank must keep rendering one buffer per
+    call (a bank rendering 8 ahead would hold the first buffer's value for all 8)."""
+    from tests.test_host_blocks import patched_parameter_patch
+    want = golden('effects_patched')['patched_parameters']
+    dur = len(want) * B / 44100. + 1e-9
+    order, banks = fusion.compile_order(determine_execution_order([patched_parameter_patch() | Dac()]))
+    assert [b.patched_params for b in banks] == [True]
+    for bank in banks:
+        bank.close()
+    got = np.concatenate(run_klang(patched_parameter_patch() | Dac(), offline=True, duration=dur,
+                                   fadeout=0., lookahead=8))
+    assert np.abs(got[:, 0] - want.ravel()).max() <= 1e-5
+    # a Gain alone, Lfo into Gain.gain, against the explicit host evaluation
+    from klang_amd.audio import Gain, Lfo
+
+    def build():
+        gain = Gain(.5)
+        Lfo(frequency=3., outputRange=(.1, 1.)) | gain.gain
+        return Oscillator(220., wave_func=sawtooth) | gain | Dac()
+    dur = 24 * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., lookahead=8))
+    host = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert np.abs(got - host).max() <= 1e-5 and np.abs(host).max() > .05
+
+
 def test_host_side_gain_edits_reach_the_device(hip):
     from klang_amd.audio import Gain
     gain = Gain(1.)

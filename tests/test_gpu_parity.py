@@ -511,8 +511,15 @@ def test_render_device_is_ordered_on_the_callers_stream(hip, ctx):
     import torch
     patch = P.polyphonic_saw_patch(n_voices=20000, n_blocks=64, off_base=20, off_span=30)
     want = hip_bank_from_patch(hip, ctx, patch).render(64)
+    busy = torch.zeros(1 << 27, dtype=torch.float32, device='cuda')
     for side in (False, True):
         stream = torch.cuda.Stream() if side else torch.cuda.current_stream()
+        if side:
+            # keep the NULL stream busy while the bank is created and rendered on the
+            # (non-blocking) side stream: the creation-time clears are ordered on the context's
+            # stream, so nothing of the bank may wait for -- or race with -- this work
+            for _ in range(40):
+                busy.add_(1.)
         with torch.cuda.stream(stream):
             c2 = hip.Context(0, stream.cuda_stream)
             bank = hip_bank_from_patch(hip, c2, patch)
