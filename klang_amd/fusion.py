@@ -253,9 +253,15 @@ class GpuVoiceBank(Block):
     """A fused set of chains evaluated by one device bank.  `sink` is the block
     whose output carries the result (the mixer, or the chain end itself)."""
 
-    def __init__(self, chains, sink, ctx=None, synths=()):
+    def __init__(self, chains, sink, ctx=None, synths=(), shard=None, dropped=()):
+        """`shard` (klang_amd.sharding.Shard): `chains` are this rank's contiguous part of the
+        mixer's inputs, `dropped` the chains other ranks evaluate.  The bank then renders the
+        UN-normalised partial bus and every render ends in one reduce over the ranks
+        (mixer.py:41-49 is the only cross-voice operation); the root divides by the global
+        input count and is the only rank whose output is the mix (the others deliver silence)."""
         super().__init__()
         self.chains, self.sink = chains, sink
+        self.shard, self.dropped = shard, list(dropped)
         # synthesizers whose voices the chains are, in voice order (synthesizer.py:151-219)
         self.synths = list(synths)
         self.poly = (self.synths[0].MAX_VOICES
@@ -286,6 +292,11 @@ class GpuVoiceBank(Block):
         if self.pairs:
             self.bank.set_mix_divisor(float(max(1, len(chains) // 2)) if len(chains) > 2 else 1.)
             self._pair_state = None
+        if self.shard is not None:
+            if self.synths or self.pairs or self.external or not self.is_mixer:
+                raise NotFusable('%s: only a mixer of uniform device chains is sharded' % sink)
+            self.bank.set_mix_divisor(1.)
+            self._shard_bus = None
         self.upstream = None    # the mono bank whose bus feeds this bank's single chain, when
                                 # there is one (compile_order): its buffers then arrive device
                                 # to device and both banks render ahead in lock-step
@@ -360,6 +371,8 @@ class GpuVoiceBank(Block):
 
     def _per_voice(self, per_input):
         """A mixer's per-input values (gains, pannings), one per bank voice."""
+        if self.shard is not None:
+            per_input = list(per_input)[self.shard.first:self.shard.first + self.shard.count]
         rep = self.poly or 1
         return [float(x) for x in per_input for _ in range(rep)]
 
@@ -438,6 +451,12 @@ class GpuVoiceBank(Block):
                     and c.filter.frequency.value != self._cutoffs[i]):
                 self._cutoffs[i] = c.filter.frequency.value
                 bank.event(i, 0, F.EV_SET_CUTOFF, 0., float(self._cutoffs[i]))
+        for c in self.dropped:      # another rank plays these voices: their notes go nowhere here
+            if c.voice is not None:
+                for _ in c.voice.input.receive():
+                    pass
+                for _ in c.envelope.input.receive():
+                    pass
         for s in range(len(self.program)):
             self._upload_stage(s)
         if self.is_mixer and not self.pairs:
@@ -474,7 +493,7 @@ class GpuVoiceBank(Block):
                 self.upstream._fresh = 0
             elif self.external:
                 self._feed_external()
-            mix = self.bank.render(ahead)
+            mix = self._render(ahead)
             self._fresh = ahead
             self._ready = [blk if self.stereo else blk[0] for blk in mix][::-1]
         if self.remaining is not None:
@@ -487,18 +506,54 @@ class GpuVoiceBank(Block):
                 rows.append(twin.sink.output.value)
             self.sink.output.set_value(np.stack(rows))
 
+    # -- voice shards (klang_amd.sharding) ----------------------------------------------
+    def _reduced(self, n_blocks):
+        """n_blocks buffers of this rank's shard, summed over the ranks on the device:
+        -> torch float32 [n_blocks][channels][256] (the mix on the root, divided by the global
+        input count; meaningless elsewhere).  One collective per call, never per buffer."""
+        import contextlib
+
+        import torch
+        from klang_amd import sharding
+        sh = self.shard
+        stream = self.ctx.stream
+        scope = (torch.cuda.stream(torch.cuda.ExternalStream(stream)) if stream
+                 else contextlib.nullcontext())
+        with scope:     # the collective is ordered behind the library's launches by the stream
+            bus = self._shard_bus
+            if bus is None or bus.shape[0] != n_blocks:
+                bus = self._shard_bus = torch.empty((n_blocks, self.bank.channels, BUFFER_SIZE),
+                                                    dtype=torch.float32, device='cuda')
+            self.bank.render_device(n_blocks, bus.data_ptr())
+            sharding.reduce_bus(bus, sh.n_total, sh.world, 0, sh.group, always=True)
+        return bus
+
+    def _render(self, n_blocks):
+        if self.shard is None:
+            return self.bank.render(n_blocks)
+        bus = self._reduced(n_blocks)
+        if self.shard.rank == 0:
+            return bus.cpu().numpy()
+        return np.zeros((n_blocks, self.bank.channels, BUFFER_SIZE), dtype=np.float32)
+
     # -- notes known ahead of time (klang_amd.klang.preschedule) ---------------------------
     def message_targets(self):
-        """{MessageInput: handle} for the inputs whose notes this bank consumes."""
+        """{MessageInput: handle} for the inputs whose notes this bank consumes (or, for the
+        voices another rank plays, swallows)."""
         if self.synths:
             return {syn.input: ('synth', i) for i, syn in enumerate(self.synths)}
-        return {c.voice.input: ('voice', i) for i, c in enumerate(self.chains)
-                if c.voice is not None}
+        targets = {c.voice.input: ('voice', i) for i, c in enumerate(self.chains)
+                   if c.voice is not None}
+        targets.update({c.voice.input: ('drop', i) for i, c in enumerate(self.dropped)
+                        if c.voice is not None})
+        return targets
 
     def schedule(self, handle, note, block):
         """What update() would do with `note` arriving in buffer `block` (counted from the
         next render), queued now."""
         F, (kind, i) = native, handle
+        if kind == 'drop':
+            return
         if kind == 'synth':
             syn = self.synths[i]
             if self.poly:
@@ -597,7 +652,16 @@ class GpuVoiceBank(Block):
         if self._ready:
             raise KlangError('GpuVoiceBank.bounce: buffers were already rendered ahead')
         self._collect_events()
-        frames, pcm, _ = self.bank.bounce(duration, fadeout, want_pcm)
+        if self.shard is not None:
+            n_cycles = int(duration * 44100 // BUFFER_SIZE)
+            bus = self._reduced(n_cycles)
+            if self.shard.rank == 0:
+                frames, pcm, _ = self.bank.bounce_bus(bus.data_ptr(), duration, fadeout, want_pcm)
+            else:           # the root writes the piece; nothing to deliver here
+                frames = np.zeros((n_cycles * BUFFER_SIZE, self.bank.channels), dtype=np.float32)
+                pcm = None
+        else:
+            frames, pcm, _ = self.bank.bounce(duration, fadeout, want_pcm)
         if self.remaining is not None:
             self.remaining = 0
         last = frames[-BUFFER_SIZE:].T.astype(np.float64)
@@ -945,19 +1009,54 @@ def link_banks(order):
             continue
         source = by_output.get(id(bank.chains[0].external))
         if (source is None or source is bank or source.stereo or source.ctx is not bank.ctx
-                or source not in banks[:k] or source._twins):
+                or source not in banks[:k] or source._twins or source.shard is not None):
+            # (a sharded bank's mix exists after the reduce, on the root: what listens to it is
+            # a post-reduce stage and takes it from the host, buffer by buffer)
             continue
         bank.upstream = source
 
 
-def compile_order(exec_order, ctx=None, strict=True):
+def shardable(sink, chains, synths, world):
+    """A group the voice sharding applies to: a Mixer / StereoMixer whose inputs are uniform
+    device chains (voices are independent until the Mixer sum), at least one per
+    rank.  Everything else is evaluated where it is."""
+    return (isinstance(sink, Mixer) and not synths and chains[0].external is None
+            and len(chains) >= world)
+
+
+def shard_groups(groups, rank, world, group=None):
+    """The plan: [(sink, kept chains, synths, Shard or None, dropped chains)] for `rank`.  A
+    shardable group keeps the contiguous part sharding.shard_range gives this rank; notes
+    addressed to the other voices are dropped HERE because their owner receives them there
+    (every rank builds the same patch, so routing by owner is keeping one's own)."""
+    from klang_amd import sharding
+    out = []
+    for sink, chains, synths in groups:
+        if shardable(sink, chains, synths, world):
+            sh = sharding.plan(len(chains), rank, world, group)
+            kept = chains[sh.first:sh.first + sh.count]
+            out.append((sink, kept, synths, sh, chains[:sh.first] + chains[sh.first + sh.count:]))
+        else:
+            out.append((sink, chains, synths, None, []))
+    return out
+
+
+def compile_order(exec_order, ctx=None, strict=True, shard=None):
     """Replace fusable chains in `exec_order` by GpuVoiceBank blocks.  With
-    strict=True every hot-path block must end up fused (KlangError otherwise)."""
+    strict=True every hot-path block must end up fused (KlangError otherwise).
+    `shard` = (rank, world[, group]): mixers of uniform device chains keep only this rank's
+    voices (shard_groups) and reduce their bus over the ranks."""
     exec_order = open_composites(exec_order)
     groups, errors = find_fusable(exec_order)
     fused_blocks, banks_at = set(), {}
-    for sink, chains, synths in groups:
-        bank = GpuVoiceBank(chains, sink, ctx, synths)
+    if shard is not None:
+        planned = shard_groups(groups, *shard)
+    else:
+        planned = [(sink, chains, synths, None, []) for sink, chains, synths in groups]
+    for sink, chains, synths, sh, dropped in planned:
+        bank = GpuVoiceBank(chains, sink, ctx, synths, shard=sh, dropped=dropped)
+        for c in dropped:
+            fused_blocks.update(c.blocks)
         for c in chains:
             fused_blocks.update(c.blocks)
         fused_blocks.update(synths)

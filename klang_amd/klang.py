@@ -40,19 +40,17 @@ def validate_global_execution_order(execOrder, logger):
                        'executed multiple times per buffer cycle!\n%s', '\n'.join(dup))
 
 
-def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', offline=False):
-    """The whole offline bounce in one device pass (klmi_bank_bounce), or None when the patch
-    is not of that kind: exactly one device bank feeding the Dac directly, nothing else in the
-    order.  Packing, fade-out and the peak-normalised int16 samples (klanggeber.py:81-97,
-    205-249, wavfile.py:54-63) then happen on the device; the host only writes the container."""
-    from klang_amd import fusion, native
+def bounce_banks(execOrder, adc, dac, duration=INF, offline=False):
+    """(banks, n_cycles) when the whole offline piece can be bounced in one device pass, else
+    None: exactly one device bank feeding the Dac directly -- or a chain of banks each fed by
+    the one before it on the device (`mixer | Reverb | Dac`) -- and nothing else in the order.
+    A pure function of the compiled order, so that every rank of a sharded run decides alike."""
+    from klang_amd import fusion
     if not offline or duration == INF or adc.nChannels:
         return None
     banks = [b for b in execOrder if isinstance(b, fusion.GpuVoiceBank)]
     if not banks or any(b not in banks and b is not dac for b in execOrder):
         return None
-    # one bank, or a chain of banks each fed by the one before it on the device
-    # (`mixer | Reverb | Dac`): the upstream banks render the whole piece, the last one bounces
     bank = banks[-1]
     if banks[0].external or any(b.upstream is not a for a, b in zip(banks, banks[1:])):
         return None
@@ -63,6 +61,22 @@ def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', of
     if (feeds != [bank.sink.output] or dac.inputs[0].incomingConnection is None
             or bank.bank.channels != dac.nChannels):
         return None
+    return banks, n_cycles
+
+
+def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', offline=False):
+    """The whole offline bounce in one device pass (klmi_bank_bounce), or None when the patch
+    is not of that kind (bounce_banks).  Packing, fade-out and the peak-normalised int16
+    samples (klanggeber.py:81-97, 205-249, wavfile.py:54-63) then happen on the device; the
+    host only writes the container."""
+    from klang_amd import native
+    found = bounce_banks(execOrder, adc, dac, duration, offline)
+    if found is None:
+        return None
+    banks, n_cycles = found
+    # one bank, or a chain of banks each fed by the one before it on the device
+    # (`mixer | Reverb | Dac`): the upstream banks render the whole piece, the last one bounces
+    bank = banks[-1]
     try:
         for upstream, downstream in zip(banks, banks[1:]):
             upstream.render_for(downstream, n_cycles)
@@ -75,6 +89,28 @@ def device_bounce(execOrder, adc, dac, duration=INF, fadeout=0., filepath='', of
         logging.getLogger('KlangGeber').info('Writing audio dump to WAV file %r', filepath)
         write_pcm(pcm, filepath)
     return list(frames.reshape(-1, BUFFER_SIZE, dac.nChannels))
+
+
+def run_shard_worker(execOrder, banks, adc, dac, duration=INF, fadeout=0., filepath='',
+                     offline=False):
+    """A rank other than the root of a sharded run: it renders its voice shards and takes part
+    in every reduce the root issues -- the same number of render calls with the same number of
+    buffers each -- and nothing else.  Blocks behind the last sharded bank (post-reduce stages:
+    `mixer | Reverb | Dac`, the Dac itself) run on the root only; no file is written here."""
+    found = bounce_banks(execOrder, adc, dac, duration, offline)
+    if found is not None:
+        found[0][-1].bounce(duration, fadeout, want_pcm=False)      # render + reduce
+        return []
+    last = max(i for i, b in enumerate(execOrder) if getattr(b, 'shard', None) is not None)
+    order = [b for b in execOrder[:last + 1] if not isinstance(b, (Adc, Dac))]
+    from klang_amd.clock import ClockMixin
+    play_time = 0.
+    for _ in range(int(duration * SAMPLING_RATE // BUFFER_SIZE)):
+        ClockMixin.set_current_time(play_time)
+        for block in order:
+            block.update()
+        play_time += INTERVAL
+    return []
 
 
 def preschedule(execOrder, banks, n_cycles):
@@ -131,10 +167,19 @@ def preschedule(execOrder, banks, n_cycles):
     return [b for b in execOrder if b not in sources]
 
 
-def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
+def run_klang(*blocks, backend='hip', lookahead=None, shard=None, **kwargs):
     """Run a block network.  kwargs: duration, fadeout, filepath, offline (see
     klang_amd.audio.engine.run_audio_engine).  Returns the list of rendered
-    float32 buffers (BUFFER_SIZE, nChannels)."""
+    float32 buffers (BUFFER_SIZE, nChannels).
+
+    Several GPUs: start one process per GPU (torchrun or any launcher that sets RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*), every one building the SAME patch and calling
+    run_klang the same way.  With a torch.distributed group of more than one rank (or
+    `shard=(rank, world[, group])`) every mixer of uniform device chains keeps only this
+    rank's contiguous range of voices (klang_amd.sharding), notes reach the rank that owns
+    their voice, each render ends in ONE reduce of the mix bus onto rank 0, and rank 0 alone
+    runs what follows the mixers, returns the frames and writes `filepath`; the other ranks
+    return []."""
     if not blocks:
         raise ValueError('No blocks to run specified!')
     if backend not in BACKENDS:
@@ -147,9 +192,22 @@ def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
         raise KlangError('Did not find any audio activity (no Adc / Dac in the patch)')
 
     banks = []
+    if shard is not None or backend == 'hip':
+        from klang_amd import sharding
+        shard = sharding.resolve(shard) if backend == 'hip' or shard is not None else None
+    if shard is not None:
+        if backend != 'hip':
+            raise KlangError("voice shards run on the device: backend='hip'")
+        if not kwargs.get('offline') or kwargs.get('duration', INF) == INF:
+            raise KlangError('a sharded run is an offline bounce with a finite duration')
     if backend == 'hip':
         from klang_amd import fusion
-        execOrder, banks = fusion.compile_order(execOrder, strict=True)
+        execOrder, banks = fusion.compile_order(execOrder, strict=True, shard=shard)
+        if shard is not None and not any(getattr(b, 'shard', None) for b in banks):
+            for bank in banks:
+                bank.close()
+            raise KlangError('nothing to shard: no mixer with at least %d uniform device chains '
+                             'in the patch' % shard[1])
         duration = kwargs.get('duration', INF)
         n_cycles = None if duration == INF else int(duration * SAMPLING_RATE // BUFFER_SIZE)
         if kwargs.get('offline'):
@@ -168,6 +226,8 @@ def run_klang(*blocks, backend='hip', lookahead=None, **kwargs):
             block.update()
 
     try:
+        if shard is not None and shard[0] != 0:
+            return run_shard_worker(execOrder, banks, adc, dac, **kwargs)
         if backend == 'hip':
             frames = device_bounce(execOrder, adc, dac, **kwargs)
             if frames is not None:

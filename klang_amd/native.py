@@ -65,7 +65,7 @@ EXPORTS = [
     'klmi_bank_render_voices',
     'klmi_bank_render_voices_f64', 'klmi_bank_render_voices_device', 'klmi_bank_reverb_state_get',
     'klmi_bank_last_kernel_ms', 'klmi_bounce_cycles', 'klmi_bank_bounce',
-    'klmi_bank_bounce_device', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
+    'klmi_bank_bounce_device', 'klmi_bank_bounce_bus', 'klmi_env_create', 'klmi_env_destroy', 'klmi_env_set',
     'klmi_env_get', 'klmi_env_gate', 'klmi_env_sample', 'klmi_env_active', 'klmi_comb_create',
     'klmi_comb_destroy', 'klmi_comb_set_alpha', 'klmi_comb_filter',
     'klmi_kick_create', 'klmi_kick_destroy', 'klmi_kick_set', 'klmi_kick_trigger',
@@ -143,6 +143,7 @@ def load():
     L.klmi_bounce_cycles.argtypes = [C.c_double]
     L.klmi_bank_bounce.argtypes = [_vp, C.c_double, C.c_double, _vp, _vp, _fp]
     L.klmi_bank_bounce_device.argtypes = [_vp, C.c_double, C.c_double, _vp, _vp, _vp]
+    L.klmi_bank_bounce_bus.argtypes = [_vp, _vp, C.c_double, C.c_double, _vp, _vp, _fp]
     L.klmi_bank_last_kernel_ms.argtypes = [_vp, _fp, C.POINTER(C.c_int)]
     L.klmi_env_create.argtypes = [_vp, C.c_int] + [C.c_double] * 6 + [C.c_int, C.c_int,
                                                                        C.POINTER(_vp)]
@@ -273,6 +274,7 @@ class Context:
         _check(load().klmi_ctx_create(int(device), _vp(stream) if stream else None,
                                       C.byref(self._h)))
         self.device = device
+        self.stream = int(stream) if stream else 0      # raw hipStream_t; 0 = the null stream
         self._children = weakref.WeakSet()
         _live_contexts.add(self)
 

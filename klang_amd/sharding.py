@@ -9,10 +9,47 @@ sums the partial buses onto the root, which applies the Mixer's division by the
 global input count.  Payload: n_blocks x channels x 1 KiB float32 per render --
 latency-bound, hence one call per render, never per block.
 """
+import collections
+import os
+
 import torch
 import torch.distributed as dist
 
 BUFFER_SIZE = 256
+
+# What one rank keeps of one mixer: `first`..`first+count` of its `n_total` inputs.
+Shard = collections.namedtuple('Shard', 'rank world n_total first count group')
+
+
+def resolve(shard=None):
+    """run_klang's `shard` argument -> (rank, world, group) or None.  `shard` may be a
+    (rank, world) pair, a (rank, world, group) triple, True ("whatever torch.distributed
+    says") or None: then the process group decides if one is initialised, and a lone
+    WORLD_SIZE > 1 in the environment (a launcher started us, nobody initialised the group
+    yet) initialises it -- backend "nccl" (RCCL) on LOCAL_RANK's GPU."""
+    if shard is None or shard is True:
+        if not dist.is_available():
+            return None
+        if not dist.is_initialized():
+            if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+                return None
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if dist.get_world_size() == 1 and shard is None:
+            return None
+        return dist.get_rank(), dist.get_world_size(), None
+    shard = tuple(shard)
+    rank, world = int(shard[0]), int(shard[1])
+    if not 0 <= rank < world:
+        raise ValueError('rank %d outside world of %d' % (rank, world))
+    return rank, world, (shard[2] if len(shard) > 2 else None)
+
+
+def plan(n_inputs, rank, world, group=None):
+    """The Shard of a mixer with n_inputs uniform chains for `rank`."""
+    first, count = shard_range(n_inputs, world, rank)
+    return Shard(rank, world, int(n_inputs), first, count, group)
 
 
 def shard_range(n_total, world_size, rank):

@@ -89,3 +89,144 @@ def test_config5_shard_of_131072_voices(hip, oracle):
     dbl.set(hip.F_GAIN, 2. * patch.gain)
     np.testing.assert_array_equal(dbl.render(nb), 2 * bus32)
     ctx.close()
+
+
+# ---- voice shards behind run_klang (klang_amd.klang.run_klang(shard=...), fusion.shard_groups)
+def _api_patch(n_voices, stereo=False, tail=None):
+    """n Voice(saw, ADSR) | Filter chains into a Mixer / StereoMixer | [tail] | Dac, one note each."""
+    from klang_amd.audio import ADSR, Dac, Filter, Mixer, Oscillator, StereoMixer, Voice, sawtooth
+    from klang_amd.messages import Note
+    mixer = StereoMixer() if stereo else Mixer()
+    for k in range(n_voices):
+        voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.005, .02, .6, .03))
+        voice.input.push(Note(20 + k, .3 + .05 * (k % 7), frequency=110. * (1 + .037 * k)))
+        mixer += voice | Filter(frequency=500. + 30. * k)
+    mixer.gains = [1. - .004 * k for k in range(n_voices)]
+    if stereo:
+        mixer.pannings = [(-1) ** k * k / n_voices for k in range(n_voices)]
+    end = mixer if tail is None else mixer | tail()
+    return end | Dac(nChannels=2 if stereo else 1)
+
+
+@pytest.fixture()
+def world_of_one():
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0,
+                            world_size=1, device_id=torch.device('cuda', 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('stereo', [False, True])
+def test_run_klang_sharded_in_a_world_of_one_equals_the_plain_bounce(hip, tmp_path, world_of_one,
+                                                                     stereo):
+    """run_klang(filepath=..., shard=(0, 1)) takes the multi-rank path -- shard plan, divisor 1,
+    render_device, RCCL reduce, division on the root, klmi_bank_bounce_bus -- and must write the
+    file the plain one-pass bounce writes.  64 inputs: the division by the input count is exact
+    in float32 and in float64, so the two roundings (here: float32 partial bus, then / 64; plain:
+    float64 sum / 64, then float32) agree bit for bit."""
+    from klang_amd.klang import run_klang
+    dur = 40 * B / 44100. + 1e-9
+    files = [str(tmp_path / name) for name in ('plain.wav', 'sharded.wav')]
+    plain = np.concatenate(run_klang(_api_patch(64, stereo), offline=True, duration=dur,
+                                     fadeout=.05, filepath=files[0]))
+    sharded = np.concatenate(run_klang(_api_patch(64, stereo), offline=True, duration=dur,
+                                       fadeout=.05, filepath=files[1], shard=(0, 1)))
+    assert plain.shape == (40 * B, 2 if stereo else 1) and np.abs(plain).max() > 1e-2
+    np.testing.assert_array_equal(sharded, plain)
+    assert open(files[0], 'rb').read() == open(files[1], 'rb').read()
+    # an input count that is not a power of two: one more float32 rounding, nothing else
+    plain = np.concatenate(run_klang(_api_patch(37, stereo), offline=True, duration=dur, fadeout=0.))
+    sharded = np.concatenate(run_klang(_api_patch(37, stereo), offline=True, duration=dur,
+                                       fadeout=0., shard=(0, 1)))
+    assert np.abs(sharded - plain).max() <= 1e-7
+
+
+def test_two_ranks_rehearsed_on_one_gpu_through_run_klang(hip, tmp_path, monkeypatch):
+    """Rank 1 and then rank 0 of a world of two, one after the other in this process, with the
+    reduce replaced by a mailbox: rank 1 (a worker: run_shard_worker) leaves its partial buses,
+    rank 0 adds them to its own in the order its reduces are issued.  The sum must be the
+    unsharded patch, the two ranks must issue the same sequence of reduces (count and shapes),
+    and only the root writes the file.  Once as a one-pass bounce (mixer | Dac) and once with a
+    post-reduce stage (mixer | Reverb | Dac: the Reverb runs on the root only)."""
+    from klang_amd import sharding
+    from klang_amd.audio import Reverb
+    from klang_amd.klang import run_klang
+    dur = 70 * B / 44100. + 1e-9
+    for tail in (None, lambda: Reverb(decay=1., dryWet=.5)):
+        mailbox, shapes = [], {0: [], 1: []}
+
+        def fake_reduce(bus, n_total, world_size, dst=0, group=None, always=False, _rank=[1]):
+            shapes[_rank[0]].append(tuple(bus.shape))
+            if _rank[0] == 1:
+                mailbox.append(bus.clone())
+            else:
+                bus += mailbox.pop(0)
+                bus /= float(n_total)
+            return bus
+        monkeypatch.setattr(sharding, 'reduce_bus', fake_reduce)
+        f1, f0 = str(tmp_path / 'r1.wav'), str(tmp_path / 'r0.wav')
+        got1 = run_klang(_api_patch(100, tail=tail), offline=True, duration=dur, fadeout=0.,
+                         filepath=f1, shard=(1, 2))
+        assert got1 == [] and not (tmp_path / 'r1.wav').exists() and mailbox
+        fake_reduce.__defaults__[-1][0] = 0
+        got0 = np.concatenate(run_klang(_api_patch(100, tail=tail), offline=True, duration=dur,
+                                        fadeout=0., filepath=f0, shard=(0, 2)))
+        assert not mailbox and shapes[0] == shapes[1] and (tmp_path / 'r0.wav').exists()
+        assert sum(s[0] for s in shapes[0]) == 70
+        monkeypatch.undo()
+        want = np.concatenate(run_klang(_api_patch(100, tail=tail), offline=True, duration=dur,
+                                        fadeout=0.))
+        assert np.abs(want).max() > 1e-2
+        assert report('run_klang sharded over 2 ranks vs one bank', np.abs(got0 - want).max()) <= 1e-6
+        (tmp_path / 'r0.wav').unlink()
+
+
+def test_sharded_run_klang_routes_prescheduled_notes_to_the_owner(hip, monkeypatch):
+    """A NoteScript in front of every voice: the notes are prescheduled on the device
+    (klang.preschedule) by the rank that owns the voice and swallowed by the other."""
+    from klang_amd import sharding
+    from klang_amd.audio import ADSR, Dac, Mixer, Oscillator, Voice, sawtooth
+    from klang_amd.klang import run_klang
+    from klang_amd.messages import Note
+    from klang_amd.notes import NoteScript
+
+    def build():
+        mixer = Mixer()
+        for k in range(6):
+            voice = Voice(Oscillator(wave_func=sawtooth), ADSR(.005, .02, .6, .01))
+            script = NoteScript({2 + k: [Note(60 + k, .5, frequency=150. * (k + 1))],
+                                 9 + k: [Note(60 + k, 0., frequency=150. * (k + 1))]})
+            script | voice
+            mixer += voice
+        return mixer | Dac()
+    dur = 24 * B / 44100. + 1e-9
+    mailbox = []
+    rank = [1]
+
+    def fake_reduce(bus, n_total, world_size, dst=0, group=None, always=False):
+        if rank[0] == 1:
+            mailbox.append(bus.clone())
+        else:
+            bus += mailbox.pop(0)
+            bus /= float(n_total)
+        return bus
+    monkeypatch.setattr(sharding, 'reduce_bus', fake_reduce)
+    assert run_klang(build(), offline=True, duration=dur, fadeout=0., shard=(1, 2)) == []
+    rank[0] = 0
+    got = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0., shard=(0, 2)))
+    monkeypatch.undo()
+    want = np.concatenate(run_klang(build(), offline=True, duration=dur, fadeout=0.))
+    assert np.abs(want).max() > 1e-2 and np.abs(got - want).max() <= 1e-6
+
+
+def test_sharding_needs_something_to_shard(hip):
+    from klang_amd.audio import Dac, Oscillator
+    from klang_amd.errors import KlangError
+    from klang_amd.klang import run_klang
+    with pytest.raises(KlangError, match='nothing to shard'):
+        run_klang(Oscillator(440.) | Dac(), offline=True, duration=.1, shard=(0, 2))
+    with pytest.raises(KlangError, match='offline'):
+        run_klang(_api_patch(4), shard=(0, 2))
