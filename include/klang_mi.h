@@ -201,13 +201,17 @@ typedef struct {
                                  are addressed to instruments with klmi_bank_notes and routed
                                  on the device (synthesizer.py:200-209).  Implies gated; the
                                  default mix divisor is P (synthesizer.py:219) */
-    int32_t reverb_rings_f64; /* storage of the Reverb's delay lines: 0 float32 (88 B of HBM
+    int32_t reverb_rings_f64; /* storage of the Reverb's delay lines: 0 float32 (80 B of HBM
                                  traffic per channel-sample with 10 combs; the comb arithmetic
                                  is float64 either way, each ring write is rounded once:
                                  measured 1.4e-7 on a channel's output), 1 float64
-                                 as in _filters.c:33 (168 B; delay lines bit-identical to the
+                                 as in _filters.c:33 (160 B; delay lines bit-identical to the
                                  reference's) */
-    int32_t reserved;
+    int32_t struct_size;      /* sizeof(klmi_chain_desc) as the CALLER compiled it, or 0 (not
+                                 checked).  klmi_bank_create refuses any other value: a client
+                                 built against an older, shorter descriptor fails loudly
+                                 instead of handing over a short struct (the descriptor grew
+                                 from 88 to 96 bytes between 0.1 and 0.2) */
 } klmi_chain_desc;
 
 /* Block-boundary events, the batched form of Voice.process_incoming_notes
@@ -335,8 +339,10 @@ int klmi_bank_render(klmi_bank *bank, int n_blocks, float *host_mix);
 int klmi_bank_render_device(klmi_bank *bank, int n_blocks, float *dev_mix);
 
 /* klmi_bank_render_device without any allocation.  It has no counterpart in the
- * reference: it is for callers that cannot allocate -- code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc.  The per-wave partial buses and
+ * reference: it is for callers that cannot allocate -- tight serving loops, harnesses that
+ * forbid hipMalloc, code under HIP graph capture (for capture two more preconditions hold,
+ * because the call otherwise synchronises the stream or sets a kernel attribute: no events /
+ * notes queued since the last render, and the bank's kernels launched once before).  The per-wave partial buses and
  * the slice sums of the bus fold, which klmi_bank_render_device keeps in buffers that grow
  * with the call, live in ONE static device array of KLMI_NOALLOC_SCRATCH_BYTES per GPU
  * (held by every GPU the library runs on until the process ends); the call makes no

@@ -56,7 +56,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *klmi_last_error(void) { return g_error.c_str(); }
-extern "C" const char *klmi_version(void) { return "klang_mi 0.1 (gfx950)"; }
+extern "C" const char *klmi_version(void) { return "klang_mi 0.3 (gfx950)"; }
 
 // ---------------------------------------------------------------------------------
 // host-side design helpers
@@ -538,6 +538,7 @@ struct klmi_bank {
     std::vector<int32_t> ring_pos;  // host-tracked, identical for every voice
     DevBuf<float> rv_partial;
     hipStream_t aux_stream = nullptr;            // dry-voice kernels of reverb banks
+    DevBuf<BankView> d_view;                     // the view, for kernels that read it in memory
     hipEvent_t rv_start = nullptr, rv_ready[2] = {nullptr, nullptr}, rv_done[2] = {nullptr, nullptr};
 
     // timing
@@ -803,6 +804,10 @@ extern "C" int klmi_bank_create(klmi_ctx *ctx, int n_voices, const klmi_chain_de
         return fail(KLMI_E_ARG, "klmi_bank_create: null argument");
     if (n_voices <= 0)
         return fail(KLMI_E_ARG, "klmi_bank_create: n_voices must be positive, got %d", n_voices);
+    if (desc->struct_size != 0 && desc->struct_size != (int32_t)sizeof(klmi_chain_desc))
+        return fail(KLMI_E_ARG, "klmi_bank_create: the caller's klmi_chain_desc is %d bytes, this "
+                                "library's (%s) is %zu: rebuild against include/klang_mi.h",
+                    desc->struct_size, klmi_version(), sizeof(klmi_chain_desc));
     if (desc->pan_mode < 0 || desc->pan_mode > 2)
         return fail(KLMI_E_ARG, "Invalid panning mode %d!", desc->pan_mode);
     if (desc->has_pan_law && desc->pan_law > 0)
@@ -2087,8 +2092,84 @@ static void launch_reverb(bool f32, bool stereo, int groups, hipStream_t st, con
 // carried by events only: ready[i] (dry bus i written), done[i] (reverb finished reading
 // dry bus i).  One reverb launch covers the whole chunk: its waves own their voices and
 // walk the chunk's time passes themselves (reverb_kernels.h).
+// Voice -> Reverb -> Mixer in one kernel (reverb_voice_kernels.h): chains without filter,
+// effect stages or modulation, the default ten combs, none shorter than a buffer.
+static bool reverb_fused_form(const klmi_bank *b)
+{
+    const char *knob = getenv("KLMI_REVERB_FUSED");   // 0: the two-kernel path (tests compare)
+    const bool enabled = !(knob && atoi(knob) == 0);
+    const klmi_chain_desc &d = b->desc;
+    return enabled && !d.has_filter && d.n_fx == 0 && d.mod_target == 0 && !d.cutoff_lfo &&
+           !d.gated && d.poly_voices == 0 && b->reverb.n_echos == 10 &&
+           b->reverb.min_length >= kReverbPass;
+}
+
+static int render_reverb_fused(klmi_bank *b, int n_blocks, float *dev_mix)
+{
+    hipStream_t st = b->ctx->stream;
+    ReverbState &r = b->reverb;
+    const bool stereo = b->desc.stereo != 0, f32 = b->desc.reverb_rings_f64 == 0;
+    const int planes = stereo ? 2 : 1;
+    // voices per wave: the kernel runs two workgroups (8 waves) per compute unit; one voice per
+    // wave while that leaves waves free, two beyond (measured at 4,096 / 16,384 channels: 1
+    // voice 10.0 / 9.9 ms, 2 voices 7.4 / 7.7 ms, 4 voices 7.6 / 10.0 ms per 512 / 128 buffers)
+    const char *vpw_knob = getenv("KLMI_REVERB_VPW");  // tuning knob (the tests run all three)
+    const int vpw_forced = vpw_knob ? atoi(vpw_knob) : 0;
+    int vpw = b->n <= 8 * b->ctx->n_cus ? 1 : 2;
+    if (vpw_forced == 1 || vpw_forced == 2 || vpw_forced == 4)
+        vpw = vpw_forced;
+    const int rows = reverb_voice_groups(b->n, vpw);   // one partial row per workgroup
+    const int slices = bus_slices(rows);
+    // buffers per launch: the partial rows of one launch stay within 256 MiB
+    static const int chunk_forced = [] {
+        const char *e = getenv("KLMI_REVERB_CHUNK");   // tuning knob
+        const int v = e ? atoi(e) : 0;
+        return v >= 1 && v <= 4096 ? v : 0;
+    }();
+    const size_t per_block = (size_t)rows * planes * kBlock * sizeof(float);
+    const int fit = (int)std::max<size_t>(1, ((size_t)256 << 20) / per_block);
+    const int chunk_blocks = std::min(n_blocks, chunk_forced ? chunk_forced : fit);
+    const size_t row_stride = (size_t)chunk_blocks * kBlock * planes;
+    HIP_TRY(b->rv_partial.reserve((size_t)rows * row_stride));
+    HIP_TRY(b->stage.reserve((size_t)slices * row_stride));
+    HIP_TRY(b->d_view.reserve(1));
+    const BankView view = make_view(b);
+    // (pageable source: the copy is staged before the call returns, `view` may die)
+    HIP_TRY(hipMemcpyAsync(b->d_view.p, &view, sizeof view, hipMemcpyHostToDevice, st));
+    b->timed_launches = 0;
+    for (int base = 0; base < n_blocks; base += chunk_blocks) {
+        const int nb = std::min(chunk_blocks, n_blocks - base);
+        const size_t bus_len = (size_t)nb * kBlock * planes;   // [block][plane][256]
+        for (int k = 0; k < r.n_echos; ++k)
+            r.position[k] = b->ring_pos[k];
+        TRY(timing_begin(b, b->timed_launches));
+        hipError_t e = launch_reverb_voice(f32, stereo, b->desc.has_env != 0, vpw, st, r, b->d_view.p,
+                                           base, b->block_clock + (uint32_t)base, nb,
+                                           b->rv_partial.p, bus_len);
+        if (e != hipSuccess)
+            return fail(KLMI_E_DEVICE, "reverb kernel launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(b->ev_stop[b->timed_launches], st));
+        b->timed_launches++;
+        for (int k = 0; k < r.n_echos; ++k)
+            b->ring_pos[k] = (int)(((long long)b->ring_pos[k] + (long long)nb * kBlock) % r.length[k]);
+        hipLaunchKernelGGL(bus_slice_kernel, dim3((unsigned)((bus_len + 1023) / 1024), slices),
+                           dim3(256), 0, st, b->rv_partial.p, rows, bus_len, b->stage.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(bus_finish_kernel, dim3((unsigned)((bus_len + 255) / 256)), dim3(256), 0,
+                           st, b->stage.p, slices, bus_len, b->mix_divisor,
+                           dev_mix + (size_t)base * planes * kBlock);
+        HIP_TRY(hipGetLastError());
+    }
+    b->block_clock += (uint32_t)n_blocks;
+    if (b->ext_input.p)
+        b->ext_cursor = std::min(b->ext_blocks, b->ext_cursor + n_blocks);
+    return 0;
+}
+
 static int render_reverb(klmi_bank *b, int n_blocks, float *dev_mix)
 {
+    if (reverb_fused_form(b))
+        return render_reverb_fused(b, n_blocks, dev_mix);
     TRY(reverb_streams(b));
     hipStream_t st = b->ctx->stream, aux = b->aux_stream;
     ReverbState &r = b->reverb;

@@ -1,7 +1,8 @@
 // launch.h -- host-side entry points of the voice kernel families.  Each family is a
 // translation unit of its own -- voice_tu.hip / voice1_tu.hip: voice_kernel in its two
 // register budgets; fm_tu.hip (three objects): its modulated forms; fx_tu.hip: voice_fx_kernel;
-// mod_tu.hip: voice_mod_kernel; pipe_tu.hip: voice_pipe_kernel -- so that the library builds
+// mod_tu.hip: voice_mod_kernel; pipe_tu.hip: voice_pipe_kernel; reverb_tu.hip:
+// reverb_voice_kernel -- so that the library builds
 // in parallel and an edit to the host code does not recompile them.  Each object holds its
 // own copy of the constant time table (upload_time_table_*).
 #pragma once
@@ -74,5 +75,15 @@ hipError_t launch_pipe_kernel(bool env, bool filt, int mode, hipStream_t st, con
                               int first, int count, int block_base, uint32_t clock_base,
                               int n_blocks, int span_total, int voices_log2, int n_cus,
                               float *partial, void *out);
+
+// reverb_voice_kernel (reverb_tu.hip): Voice -> Reverb -> Mixer fused, for chains without
+// filter, stages or modulation and the default ten combs of >= 256 samples; vpw in {1, 2, 4}.
+// One partial row per workgroup: reverb_voice_groups(n, vpw) rows.  dev_view: the bank's view
+// in DEVICE memory (the kernel reads it there).
+struct ReverbState;
+int reverb_voice_groups(int n_voices, int vpw);
+hipError_t launch_reverb_voice(bool rings_f32, bool stereo, bool env, int vpw, hipStream_t st,
+                               const ReverbState &r, const BankView *dev_view, int block_base,
+                               uint32_t clock_base, int n_blocks, float *partial, size_t row_stride);
 
 }  // namespace klmi

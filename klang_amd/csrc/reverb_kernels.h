@@ -21,10 +21,14 @@
 // consecutive samples (a "pass", 256 here) depend only on ring contents written before
 // the pass.  A WAVEFRONT owns a few voices for the whole launch: lane l handles samples
 // 4l .. 4l+3 of the pass for each of its voices in turn, then moves on to the next pass.
-// What a pass reads was written at least five passes earlier BY THE SAME WAVE (program
-// order is all the ordering needed), voices never interact, so there is no barrier and no
-// launch boundary along time: one launch covers any number of buffers, and the memory
-// latency of one wave is hidden by the other waves of the compute unit.
+// What a pass reads was written BY THE SAME WAVE in an earlier pass -- at least five passes
+// earlier with the default 30 ms pre-delay, in the immediately preceding pass (by another lane)
+// when the shortest comb is only 257..511 samples long.  Vector memory operations of one
+// wavefront reach the cache in program order, which is all the ordering needed
+// (tests/test_gpu_reverb_scale.py pins the 6 ms regime bit for bit against the oracle); voices
+// never interact, so there is no barrier and no launch boundary along time: one launch covers
+// any number of buffers, and the memory latency of one wave is hidden by the other waves of
+// the compute unit.
 // Reverbs whose shortest comb is below 256 samples (preDelay < 6 ms) or that have another
 // number of combs than the default 10 take reverb_short_kernel: one sample per lane,
 // passes of at most 64 samples.

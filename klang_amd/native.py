@@ -83,7 +83,7 @@ class ChainDesc(C.Structure):
                 ('reverb_n_echos', C.c_int32), ('cutoff_lfo', C.c_int32),
                 ('mod_target', C.c_int32), ('n_fx', C.c_int32), ('fx', C.c_uint8 * 8),
                 ('gated', C.c_int32), ('poly_voices', C.c_int32),
-                ('reverb_rings_f64', C.c_int32), ('reserved', C.c_int32)]
+                ('reverb_rings_f64', C.c_int32), ('struct_size', C.c_int32)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -332,7 +332,7 @@ class Bank:
                               int(cutoff_lfo), int(mod_target), len(effects),
                               (C.c_uint8 * 8)(*(effects + [0] * (MAX_FX - len(effects)))),
                               int(gated), int(poly_voices),
-                              int(reverb.get('rings', 'f32') == 'f64'), 0)
+                              int(reverb.get('rings', 'f32') == 'f64'), C.sizeof(ChainDesc))
         self.effects = effects
         self.ctx = ctx
         self.n = int(n_voices)

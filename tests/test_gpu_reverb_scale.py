@@ -174,3 +174,81 @@ def test_float32_ring_storage_measured(hip, ctx, oracle, golden):
     report('reverb (float32 ring storage, comb outputs in the delay lines)', ring_err)
     assert np.abs(wet).max() > .3
     assert out_err <= 2e-6 and ring_err <= 5e-6
+
+
+@pytest.mark.parametrize('stereo', [False, True])
+def test_fused_voice_reverb_kernel_equals_the_two_kernel_path(hip, ctx, monkeypatch, stereo):
+    """reverb_voice_kernel (dry voice made inside the reverb wave, 1 / 2 / 4 voices per wave)
+    against the voice kernel + reverb_kernel pair on a random bank with float64 rings: delay
+    lines, ring positions and every voice state bit for bit, the mix to the float32 rounding of
+    the different fold (per workgroup instead of per wave)."""
+    n, spans = 1501, (3, 1, 7, 6)
+    rng = np.random.default_rng(11)
+    patch = P.reverb_patch(n_channels=n, n_blocks=sum(spans), period=5, note_blocks=2)
+    patch['reverb'] = dict(patch['reverb'], rings='f64')
+    patch['wave'] = rng.integers(0, 5, n).astype(np.int32)       # sine .. PWM
+    patch['attack'] = .001 + .02 * rng.random(n)
+    patch['decay'] = .05 * rng.random(n)
+    patch['sustain'] = .2 + .8 * rng.random(n)
+    patch['release'] = .002 + .05 * rng.random(n)
+    patch['loop'] = rng.random(n) < .3
+    patch['retrigger'] = rng.random(n) < .5
+    patch['gain'] = .5 + rng.random(n)
+    patch['stereo'] = stereo
+    patch['pan'] = rng.uniform(-1., 1., n)
+    ev = patch.events.copy()
+    ev['frequency'] *= 1. + .5 * rng.random(len(ev))
+    ev['velocity'] = np.where(ev['kind'] == hip.EV_NOTE_ON, .2 + .8 * rng.random(len(ev)), 0.)
+    patch['events'] = ev
+
+    def run(fused, vpw):
+        monkeypatch.setenv('KLMI_REVERB_FUSED', '1' if fused else '0')
+        monkeypatch.setenv('KLMI_REVERB_VPW', str(vpw))
+        bank = hip_bank_from_patch(hip, ctx, patch)
+        bank.set(hip.F_DUTY, .1 + .8 * np.random.default_rng(3).random(n))
+        mix = np.concatenate([bank.render(k) for k in spans])
+        state = [bank.get_state(f) for f in (hip.F_PHASE, hip.F_ENV_VALUE, hip.F_ENV_STAGE,
+                                             hip.F_ENV_ENABLED, hip.F_FREQUENCY, hip.F_AMPLITUDE)]
+        rings = [bank.reverb_state(v) for v in (0, 1, 2, 3, 700, n - 2, n - 1)]
+        bank.close()
+        return mix, state, rings
+    want_mix, want_state, want_rings = run(False, 1)
+    assert np.abs(want_mix).max() > 1e-3
+    for vpw in (1, 2, 4):
+        mix, state, rings = run(True, vpw)
+        assert np.abs(mix - want_mix).max() <= 2e-7
+        for got, ref in zip(state, want_state):
+            np.testing.assert_array_equal(got, ref)
+        for (got, gpos), (ref, rpos) in zip(rings, want_rings):
+            assert list(gpos) == list(rpos)
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('fused', ['1', '0'])
+def test_combs_barely_longer_than_a_pass_vs_oracle_bit_exact(hip, ctx, oracle, monkeypatch, fused):
+    """pre_delay = 6 ms: the shortest comb is 269 samples, so a 256-sample pass reads slots that
+    the SAME wave stored in the pass before, through another lane (and through the mirror /
+    second-store slots at the ring's end).  Float64 rings under a sawtooth are plain float64
+    arithmetic end to end: delay lines and positions must equal the oracle's bit for bit, in
+    the fused kernel and in the two-kernel path, one voice per wave."""
+    n, nb = 70, 9
+    monkeypatch.setenv('KLMI_REVERB_FUSED', fused)
+    monkeypatch.setenv('KLMI_REVERB_VPW', '1')
+    patch = P.reverb_patch(n_channels=n, n_blocks=nb, period=4, note_blocks=2)
+    patch['reverb'] = dict(decay=2., pre_delay=.006, dry_wet=.6, n_echos=10, rings='f64')
+    patch['wave'] = np.full(n, P.WAVE_SAWTOOTH, dtype=np.int32)
+    taps, _ = hip.reverb_design(2., .006, 10)
+    assert 256 < min(taps) < 512
+    wet, reverbs = oracle_reverb_channels(oracle, hip, patch, nb)
+    want = wet.sum(axis=0).reshape(nb, B) / n
+    bank = hip_bank_from_patch(hip, ctx, patch)
+    mix = np.concatenate([bank.render(k) for k in (4, 5)])
+    assert np.abs(want).max() > 1e-2 and np.abs(mix[:, 0, :] - want).max() <= 1e-6
+    for v in (0, 1, 33, n - 1):
+        rings, pos = bank.reverb_state(v)
+        o_rings, o_pos = oracle_rings(reverbs[v])
+        assert list(pos) == o_pos
+        for got, ref in zip(rings, o_rings):
+            np.testing.assert_array_equal(got, ref)
+    bank.close()

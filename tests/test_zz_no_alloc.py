@@ -31,8 +31,13 @@ def _render_pair(hip, ctx, patch, spans, **kw):
         parts = []
         for nb in spans:
             bus = torch.full((nb, bank.channels, B), 3., dtype=torch.float32, device='cuda')
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]
             getattr(bank, entry)(nb, bus.data_ptr())
             ctx.synchronize()
+            if entry == 'render_device_noalloc':
+                # hipMemGetInfo: the call took no device memory (a stray reserve() would show)
+                assert torch.cuda.mem_get_info()[0] == free_before
             parts.append(bus.cpu().numpy())
         out.append((np.concatenate(parts), bank.get_state(hip.F_PHASE), bank.get_state(hip.F_Z0)))
         bank.close()
@@ -95,3 +100,21 @@ def test_noalloc_splits_long_calls_and_rejects_what_does_not_fit(hip, ctx):
         huge.render_device_noalloc(1, bus.data_ptr())
     assert e.value.code == hip.E_ARG and 'scratch' in str(e.value)
     huge.close()
+
+
+def test_noalloc_covers_the_pipelined_kernel_and_compiled_effect_programs(hip, ctx):
+    """Small banks take voice_pipe_kernel, Filter -> Tremolo -> Gain chains voice_fx_kernel:
+    both through the no-allocation entry point, bit-equal to the allocating one."""
+    small = P.polyphonic_saw_patch(n_voices=3000, n_blocks=20, off_base=5, off_span=10)
+    (got, ph, z0), (want, wph, wz0) = _render_pair(hip, ctx, small, (12, 8))
+    assert np.abs(want).max() > 1e-3
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(ph, wph)
+    np.testing.assert_array_equal(z0, wz0)
+    fx = P.polyphonic_saw_patch(n_voices=30000, n_blocks=12, off_base=4, off_span=6)
+    kw = dict(effects=[hip.FX_FILTER, hip.FX_TREMOLO, hip.FX_GAIN])
+    (got, ph, z0), (want, wph, wz0) = _render_pair(hip, ctx, fx, (7, 5), **kw)
+    assert np.abs(want).max() > 1e-3
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(ph, wph)
+    np.testing.assert_array_equal(z0, wz0)

@@ -175,22 +175,30 @@ def config_synth(ctx):
 def config4(ctx, n_channels=4096, n_blocks=512, rings='f64'):
     patch = patches.reverb_patch(n_channels=n_channels, n_blocks=n_blocks)
     patch['reverb'] = dict(patch['reverb'], rings=rings)
+    if os.environ.get('KLANG_BENCH_NOENV') == '1':      # experiment: plain oscillators
+        patch['has_env'] = False
     bank, ev = bank_for(ctx, patch)
     queue(bank, ev, n_blocks, 5)
     best, med = timed(lambda: bank.render(n_blocks))
     ms, launches = bank.last_kernel_ms()
     units = n_channels * n_blocks * B
     width = 4 if rings == 'f32' else 8
-    per_sample = 10 * 2 * width + 8.   # 10 combs x (read + write) of a ring slot + 8 B dry input
+    # 10 combs x (read + write) of a ring slot.  The dry signal is made inside the
+    # reverb wave (KLMI_REVERB_FUSED=0: the two-kernel path, + 8 B written + 8 B read of dry bus)
+    per_sample = 10 * 2 * width
+    fused = os.environ.get('KLMI_REVERB_FUSED', '1') != '0'
     algo = units * per_sample
     return dict(config='4: %d channels Voice(sine, AR(.01,1.)) -> Reverb(decay 3, dryWet .7) -> '
                        'Mixer, %d blocks, %s rings (%.2f GB of delay lines)'
                        % (n_channels, n_blocks, rings, n_channels * 13896 * width / 1e9),
                 value=units / med, unit='channel-samples/s', wall_ms=med * 1e3,
                 reverb_kernel_ms=ms, reverb_launches=launches,
+                dry_bus_bytes_per_channel_sample=0 if fused else 16,
+                knobs={k: v for k, v in os.environ.items() if k.startswith(('KLMI_', 'KLANG_BENCH'))},
                 roofline=dict(bound='hbm', achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK,
                               unit='GB/s', frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK,
-                              kernel='reverb_kernel', algorithmic_bytes_per_channel_sample=per_sample,
+                              kernel='reverb_voice_kernel' if fused else 'reverb_kernel',
+                              algorithmic_bytes_per_channel_sample=per_sample,
                               whole_call_frac=algo / med / 1e9 / HBM_PEAK))
 
 
