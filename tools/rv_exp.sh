@@ -1,12 +1,9 @@
 set -e
 mkdir -p gpurun_out
 : > gpurun_out/rv_exp.jsonl
-timeout -k 10 300 python -u -m pytest tests/test_gpu_reverb_scale.py tests/test_zz_no_alloc.py -x -q --timeout 180 --timeout-method thread > gpurun_out/rv_tests.log 2>&1 || { tail -30 gpurun_out/rv_tests.log; exit 1; }
-tail -2 gpurun_out/rv_tests.log
-for occ in 3 2; do
+KLMI_REVERB_FUSED=0 timeout -k 10 120 python tools/bench_configs.py 4 4big >> gpurun_out/rv_exp.jsonl
 for vpw in 1 2 4; do
-KLMI_REVERB_OCC=$occ KLMI_REVERB_VPW=$vpw timeout -k 10 120 python tools/bench_configs.py 4f32 4bigf32 >> gpurun_out/rv_exp.jsonl
-done
+KLMI_REVERB_VPW=$vpw timeout -k 10 120 python tools/bench_configs.py 4 4big >> gpurun_out/rv_exp.jsonl
 done
 python - <<'PY'
 import json
