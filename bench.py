@@ -108,10 +108,12 @@ def extra_records(ctx, native, patches, torch, log):
     bank.close()
     log('materialised: %.3g voice-samples/s, %.0f GB/s' % (units / (ms * 1e-3), gbs))
 
-    # -- BASELINE configs[3]: 4,096 reverb channels, delay lines in HBM
-    n, nb = 4096, 512
-    patch = patches.reverb_patch(n_channels=n, n_blocks=nb)
-    for rings, per_sample in (('f32', 88.), ('f64', 168.)):
+    # -- BASELINE configs[3]: reverb channels, delay lines in HBM.  A4 = 10 combs x
+    # (read + write) x ring width; the dry voice is made inside the reverb wave, so no dry bus
+    # moves through HBM (dry_bus_bytes_per_channel_sample: 0; the two-kernel path moved 16)
+    for n, nb, rings in ((4096, 512, 'f32'), (16384, 128, 'f32'), (4096, 512, 'f64')):
+        per_sample = 80. if rings == 'f32' else 160.
+        patch = patches.reverb_patch(n_channels=n, n_blocks=nb)
         patch['reverb'] = dict(patch['reverb'], rings=rings)
         bank = native.Bank(ctx, n, has_env=True, has_reverb=True, reverb=patch['reverb'])
         assert bank.desc.reverb_rings_f64 == (rings == 'f64')
@@ -123,7 +125,8 @@ def extra_records(ctx, native, patches, torch, log):
         ms, wall_ms = stats(kern)['median'], stats([w * 1e3 for w in wall])
         gbs = units * per_sample / (ms * 1e-3) / 1e9
         whole = units * per_sample / (wall_ms['median'] * 1e-3) / 1e9
-        out['config4_rings_' + rings] = {
+        key = 'config4_rings_' + rings + ('' if n == 4096 else '_%d' % n)
+        out[key] = {
             'workload': 'configs[3]: %d channels Voice(sine, AR(.01,1.)) -> Reverb(decay 3, dryWet .7) '
                         '-> Mixer, %d blocks, %s ring storage (%.2f GB of delay lines)'
                         % (n, nb, rings, n * 13896 * (4 if rings == 'f32' else 8) / 1e9),
@@ -133,10 +136,11 @@ def extra_records(ctx, native, patches, torch, log):
                          'frac': gbs / HBM_PEAK_GBS, 'whole_call_frac': whole / HBM_PEAK_GBS,
                          'frac_of_probe_update': gbs / rates['update'],
                          'algorithmic_bytes_per_channel_sample': per_sample,
-                         'kernel': 'reverb_kernel'}}
+                         'dry_bus_bytes_per_channel_sample': 0.,
+                         'kernel': 'reverb_voice_kernel'}}
         bank.close()
-        log('config4 %s rings: %.3g channel-samples/s, kernel %.0f GB/s' %
-            (rings, units / (wall_ms['median'] * 1e-3), gbs))
+        log('config4 %d ch %s rings: %.3g channel-samples/s, kernel %.0f GB/s' %
+            (n, rings, units / (wall_ms['median'] * 1e-3), gbs))
     return out
 
 

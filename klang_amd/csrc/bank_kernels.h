@@ -317,6 +317,9 @@ __global__ __launch_bounds__(kGroup, OCC) void voice_kernel(BankView bk, int fir
     const bool live = local < count;
     const int v = first + (live ? local : 0);
 
+    TauConsts tc = {kInvTau, kTau, 2. * kInvTau, kPi};   // opaque to the optimiser: dsp_device.h
+    asm volatile("" : "+s"(tc.inv_tau), "+s"(tc.tau), "+s"(tc.inv_pi), "+s"(tc.pi));
+
     // ---- load parameters and state ------------------------------------------------
     double freq = bk.frequency_rw[v];
     double amp = bk.amplitude_rw[v];
@@ -593,6 +596,13 @@ __global__ __launch_bounds__(kGroup, OCC) void voice_kernel(BankView bk, int fir
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             osc[j] = bk.ext_input[(size_t)(block_base * kBlock + s0 + i8 + j) * bk.n + v];
+                        // Waited for on the spot (vmcnt 0).  Left pending, these eight loads reach
+                        // the chunk loop's head as "maybe in flight" for the registers that every
+                        // other wave-function variant computes its samples into, and the compiler
+                        // then guards each of the eight samples of EVERY variant's straight-line
+                        // region with an s_waitcnt vmcnt(7..0): eight no-op waits per group, each
+                        // an issue slot of the lone wave of a 65,536-voice bank.
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
                     } else if (wsel == W_ONE) {
 #pragma unroll
                         for (int j = 0; j < G; ++j)
@@ -653,10 +663,10 @@ __global__ __launch_bounds__(kGroup, OCC) void voice_kernel(BankView bk, int fir
                             } else if constexpr (FM) {
                                 osc[j] = fm_sample(wsel, tt.t[j]);
                             } else if constexpr (FAST) {
-                                const double k = floor(arg[j] * kInvTau);
-                                const double ph = __builtin_fma(-k, kTau, arg[j]);
+                                const double k = floor(arg[j] * tc.inv_tau);
+                                const double ph = __builtin_fma(-k, tc.tau, arg[j]);
                                 hi_max = max(hi_max, (uint32_t)__double2hiint(ph));
-                                osc[j] = wave_eval<true>(wsel, ph, duty_edge);
+                                osc[j] = wave_eval_wrapped(wsel, ph, duty_edge, tc);
                             } else {
                                 osc[j] = wave_eval<false>(wsel, np_mod_tau(arg[j]), duty_edge);
                             }

@@ -106,6 +106,27 @@ __device__ __forceinline__ double div_pi(double a)
     return __builtin_fma(r, kInvPi, q);
 }
 
+// The four constants of the remainder and the two divisions, as run-time values.  As
+// literals the compiler notices that TAU / PI and 1/TAU / (2/TAU) share their low words,
+// keeps one copy of each low word and re-assembles the four register pairs with scalar moves
+// in every trip through the sample loop; handed over as opaque values (see voice_kernel) they
+// are four plain register pairs.  Same numbers, same operations, same results.
+struct TauConsts {
+    double inv_tau, tau, inv_pi, pi;
+};
+__device__ __forceinline__ double div_tau(double a, const TauConsts &c)
+{
+    const double q = a * c.inv_tau;
+    const double r = __builtin_fma(-q, c.tau, a);
+    return __builtin_fma(r, c.inv_tau, q);
+}
+__device__ __forceinline__ double div_pi(double a, const TauConsts &c)
+{
+    const double q = a * c.inv_pi;
+    const double r = __builtin_fma(-q, c.pi, a);
+    return __builtin_fma(r, c.inv_pi, q);
+}
+
 // 0 <= p < TAU as ONE integer compare: non-negative doubles order like their
 // bit patterns, and any set sign bit (negative values, -0.0) compares high.
 __device__ __forceinline__ bool in_zero_tau(double p)
@@ -132,6 +153,30 @@ __device__ __forceinline__ double wave_eval(int wave, double p, double duty_edge
     case W_TRIANGLE: {
         const double w = wrap_shifted(p) - kPi;
         double q = div_tau(4. * w);
+        q = q < 0. ? q + 4. : q;                    // % 4 (NumPy sign rule)
+        return 1. - fabs(q - 2.);
+    }
+    case W_PWM:
+        return (p < duty_edge) ? 1. : -1.;
+    default:
+        return 1.;
+    }
+}
+
+// wave_eval<true> with the constants handed over (the fast kernel's straight-line region)
+__device__ __forceinline__ double wave_eval_wrapped(int wave, double p, double duty_edge,
+                                                    const TauConsts &c)
+{
+    switch (wave) {
+    case W_SINE:
+        return sin_wrapped(p);
+    case W_SQUARE:
+        return (wrap_shifted(p) - kPi >= 0.) ? 1. : -1.;
+    case W_SAWTOOTH:
+        return div_pi(p, c) - 1.;   // 2. * m / TAU - 1.
+    case W_TRIANGLE: {
+        const double w = wrap_shifted(p) - kPi;
+        double q = div_tau(4. * w, c);
         q = q < 0. ? q + 4. : q;                    // % 4 (NumPy sign rule)
         return 1. - fabs(q - 2.);
     }
