@@ -60,9 +60,11 @@ struct BankView {
     const double *fx_par;      // [8][kFxSlots][n] per-stage device parameters
     double *fx_state;          // [8][2][n]: tremolo lfo phase, zi; delay position; ring modulator
                                // lfo phase, modulator phase
-    double *fx_ring;           // the delay stage's lines, [n][fx_ring_stride] (voice-major: ring
-                               // positions differ per voice); slots [len, len+8) mirror [0, 8)
+    double *fx_ring;           // the delay stage's lines: tiles[(t / 8) % fx_ring_tiles][n][8] by
+                               // absolute sample time t (delay_tiles below), or, block-major,
+                               // [n][fx_ring_stride] RingBuffer arrays
     int fx_ring_stride;
+    int fx_ring_tiles;
     // some voice's delay line is shorter than one buffer: the lines are RingBuffer data arrays
     // ([length slots][256 tail]) and the Delay runs block-major (mod_kernels.h delay_block)
     int fx_block_major;
@@ -237,6 +239,50 @@ __device__ __forceinline__ void flush_chunk(typename TileTraits<MODE>::T *tile, 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// ---- Delay lines tiled by absolute time (effects.py:136-174, ring_buffer.py:62-109) -----------
+// tiles[(t / 8) % T][voice][t % 8]: the sample a voice wrote at absolute time t.  The delayed
+// sample of time t is the one written at t - length (zero before the line's start: the tiles
+// start as zeros and a voice's column is cleared when its length changes), so a voice needs
+// no position in memory.  A wavefront's eight new samples are ONE contiguous 4 KiB piece of a
+// tile row; its eight delayed samples lie in two neighbouring tile rows, contiguous across the
+// lanes whenever the voices' delay times agree.  T >= longest / 8 + 3: the tile being written
+// is never one being read.
+struct DelayTap {
+    const double *cur_base;   // (tile holding t0 - length) - r: element j >= r of the group is cur_base[j]
+    const double *prev_base;  // (the tile before it) + 8 - r:   element j <  r is prev_base[j]
+    int r;
+};
+
+// The eight samples written `length` = 8 q + r samples before group `g` (tile index, already
+// reduced modulo T) of voice v; q < T - 2.
+__device__ __forceinline__ void delay_read8(const double *tiles, size_t n, int T, int g, int q, int r,
+                                            int v, double (&old)[8])
+{
+    int tc = g - q;
+    tc = tc < 0 ? tc + T : tc;
+    int tp = tc - 1;
+    tp = tp < 0 ? tp + T : tp;
+    const double *pc = tiles + ((size_t)tc * n + (size_t)v) * 8 - r;
+    const double *pp = tiles + ((size_t)tp * n + (size_t)v) * 8 + 8 - r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        old[j] = (j >= r ? pc : pp)[j];
+}
+
+__device__ __forceinline__ void delay_write8(double *tiles, size_t n, int g, int v, const double (&w)[8])
+{
+    double2 *dst = reinterpret_cast<double2 *>(tiles + ((size_t)g * n + (size_t)v) * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        dst[j] = make_double2(w[2 * j], w[2 * j + 1]);
+}
+
+// tile index of the first sample of absolute block `clock`: (clock * 32) % T
+__device__ __forceinline__ int delay_tile_of_block(uint32_t clock, int T)
+{
+    return (int)(((unsigned long long)clock * (kBlock / 8)) % (unsigned)T);
 }
 
 // Lfo(shape=1) | Filter.frequency, once per block (oscillators.py:175-181,

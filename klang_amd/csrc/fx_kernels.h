@@ -129,16 +129,17 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
         trem_z = bk.fx_state[(size_t)(2 * (FIRST_STAGE + TREM) + 1) * n + v];
     }
     const double trem_floor = 1. - trem_depth;
-    // Delay (effects.py:136-174): the voice's own line, slots [len, len + 8) mirror [0, 8)
-    int delay_pos = 0, delay_len = 1;
+    // Delay (effects.py:136-174): lines tiled by absolute time (bank_kernels.h delay_read8);
+    // the position is carried only as the state the reference's RingBuffer would report
+    int delay_pos = 0, delay_len = 1, delay_q = 0, delay_r = 0;
     double delay_fb = 0., delay_dw = 0.;
-    double *delay_line = nullptr;
+    const int delay_tiles = bk.fx_ring_tiles;
     if constexpr (DELAY >= 0) {
         const double *par = bk.fx_par + (size_t)((FIRST_STAGE + DELAY) * kFxSlots) * n + v;
         delay_pos = (int)bk.fx_state[(size_t)(2 * (FIRST_STAGE + DELAY)) * n + v];
         delay_len = (int)par[0];
+        delay_q = delay_len >> 3, delay_r = delay_len & 7;
         delay_fb = par[n], delay_dw = par[2 * n];
-        delay_line = bk.fx_ring + (size_t)v * bk.fx_ring_stride;
     }
     const double delay_dry = 1. - delay_dw;
     // Gain stages (effects.py:58-70): one parameter each
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
 
     for (int b = 0; b < n_blocks; ++b) {
         const uint32_t abs_block = clock_base + (uint32_t)b;
+        const int block_tile = DELAY >= 0 ? delay_tile_of_block(abs_block, delay_tiles) : 0;
         while (next_ev <= abs_block) {  // voices.py:55-64: notes at the block boundary
             const uint32_t kind = bk.ev_kind[ev_i];
             if (kind == 1u) {
@@ -278,16 +280,11 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
                 const Time8 tt = times[i8 >> 3];
                 // the Delay's eight delayed samples, asked for first
                 double old[G] = {};
-                int idx0 = 0;
+                int ttile = 0;   // wave-uniform: the time tile of this group
                 if constexpr (DELAY >= 0) {
-                    idx0 = delay_pos + c * CH + i8;
-                    idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
-                    const DoublePair *line = reinterpret_cast<const DoublePair *>(delay_line + idx0);
-#pragma unroll
-                    for (int j = 0; j < G; j += 2) {
-                        const DoublePair o = line[j >> 1];
-                        old[j] = o.a, old[j + 1] = o.b;
-                    }
+                    ttile = block_tile + ((c * CH + i8) >> 3);
+                    ttile = ttile >= delay_tiles ? ttile - delay_tiles : ttile;
+                    delay_read8(bk.fx_ring, n, delay_tiles, ttile, delay_q, delay_r, v, old);
                 }
 
                 double osc[G];
@@ -387,23 +384,8 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             w[j] = y[j] + delay_fb * old[j];
-                        if (live) {
-                            DoublePair *line = reinterpret_cast<DoublePair *>(delay_line + idx0);
-#pragma unroll
-                            for (int j = 0; j < G; j += 2)
-                                line[j >> 1] = DoublePair{w[j], w[j + 1]};
-                            // keep slots and mirror in step where the 8 touch either end
-                            if (idx0 < 8 || idx0 + G > delay_len) {
-#pragma unroll
-                                for (int j = 0; j < G; ++j) {
-                                    const int idx = idx0 + j;
-                                    if (idx >= delay_len)
-                                        delay_line[idx - delay_len] = w[j];
-                                    else if (idx < 8)
-                                        delay_line[idx + delay_len] = w[j];
-                                }
-                            }
-                        }
+                        if (live)
+                            delay_write8(bk.fx_ring, n, ttile, v, w);
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             y[j] = delay_dry * y[j] + delay_dw * w[j];

@@ -482,8 +482,11 @@ struct klmi_bank {
     DevBuf<double> fx_par, fx_ring, fx_ring_backup;
     int fx_ring_cap = 0;                 // longest line the allocation holds; 0 = not allocated yet
     bool fx_ring_dirty = true;           // a delay time was set since the lines were last sized
-    int fx_ring_stride = 0;              // doubles per voice row: capacity + 8 mirror slots,
-                                         // rounded up to whole 128-byte lines
+    int fx_ring_stride = 0;              // block-major layout (a line shorter than a buffer):
+                                         // doubles per voice row, [length slots][256 tail]
+    int fx_ring_tiles = 0;               // tiled layout (all lines >= one buffer): time tiles of 8
+                                         // samples held, [tile][voice][8] by ABSOLUTE sample time
+    size_t fx_ring_len = 0;              // doubles allocated to the lines, either layout
     int fx_delay_stage = -1;
     // some line is shorter than one buffer: lines are [length][256 tail], the Delay runs
     // block-major through a staging area of [waves][2][256][64] doubles (mod_kernels.h)
@@ -596,6 +599,7 @@ static BankView make_view(klmi_bank *b)
     v.fx_state = b->desc.n_fx ? b->f64(SL_FX_STATE) : nullptr;
     v.fx_ring = b->fx_ring.p;
     v.fx_ring_stride = b->fx_ring_stride;
+    v.fx_ring_tiles = b->fx_ring_tiles;
     v.fx_block_major = b->fx_block_major ? 1 : 0;
     v.fx_stage = b->fx_stage.p;
     v.gated = b->desc.gated || b->desc.poly_voices > 0;
@@ -703,9 +707,34 @@ static int upload_fx(klmi_bank *b, int stage, int first, int count)
     return 0;
 }
 
-// The delay stage's lines [n][stride], stride >= the longest line of the bank + 8 mirror
-// slots, zero-initialised (ring_buffer.py:42).  Sized when a delay time was set since the last
-// render; an allocation that is too short grows and keeps what the lines hold.
+// Line lengths (samples) the Delay stage would have with `times` for voices [first, first+count)
+// and the bank's current times elsewhere: -> longest line, and whether any is shorter than a buffer.
+static void delay_line_shape(const klmi_bank *b, int first, int count, const double *times,
+                             int *longest, bool *any_short)
+{
+    const size_t n = (size_t)b->n;
+    const double *cur = &b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n];
+    *longest = 0;
+    *any_short = false;
+    for (size_t v = 0; v < n; ++v) {
+        const bool edited = times && (int)v >= first && (int)v < first + count;
+        const int len = (int)((edited ? times[v - first] : cur[v]) * KLMI_SAMPLING_RATE);
+        *longest = std::max(*longest, len);
+        *any_short = *any_short || len < KLMI_BUFFER_SIZE;
+    }
+}
+
+// The delay stage's lines, zero-initialised (ring_buffer.py:42), in one of two layouts fixed by
+// the bank's first render:
+//  * tiled by ABSOLUTE time (every line >= one buffer): tiles[(t / 8) % T][voice][t % 8], t =
+//    samples since the bank was created.  What a voice reads at time t is what it wrote at
+//    t - length, so no per-voice position exists in memory: every write of a wavefront is one
+//    contiguous 4 KiB row piece, and so is every read of voices with equal delay times
+//    (T = longest line / 8 + 3 tiles);
+//  * the RingBuffer's own data array per voice, [n][length slots + 256 tail] (some line is
+//    shorter than one buffer: mod_kernels.h delay_block).
+// Sized when a delay time was set since the last render; an allocation that is too short
+// grows and keeps what the lines hold.
 static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
 {
     if (b->fx_delay_stage < 0 || !b->fx_ring_dirty)
@@ -713,14 +742,8 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
     const size_t n = (size_t)b->n;
     int need = 0;
     bool any_short = false;
-    for (size_t v = 0; v < n; ++v) {
-        const int len = (int)(b->fx_raw[((size_t)b->fx_delay_stage * KLMI_FX_PARAMS) * n + v] *
-                              KLMI_SAMPLING_RATE);
-        need = std::max(need, len);
-        any_short = any_short || len < KLMI_BUFFER_SIZE;
-    }
-    // The two line layouts (8 mirror slots / the RingBuffer's tail of one buffer) do not
-    // convert into each other once the lines hold samples.
+    delay_line_shape(b, 0, 0, nullptr, &need, &any_short);
+    // (klmi_bank_set_params refuses edits that would change the layout of lines in use)
     if (b->fx_ring_cap > 0 && any_short != b->fx_block_major)
         return fail(KLMI_E_STATE, "Delay times shorter than one buffer (%d samples) have to be set "
                                   "before the bank's first render, for all voices at once, and "
@@ -733,7 +756,6 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
         return fail(KLMI_E_STATE, "the Delay stage's lines are not allocated yet (or a longer "
                                   "time was set): one allocating render (or preview) must come first");
     hipStream_t st = b->ctx->stream;
-    const int stride = (need + (any_short ? KLMI_BUFFER_SIZE : 8) + 15) & ~15;
     if (any_short && !b->fx_stage.p) {
         const size_t waves = ((size_t)b->n + kGroup - 1) / kGroup * kWavesPerGroup;
         hipError_t se = b->fx_stage.alloc(waves * 2 * kBlock * 64);
@@ -742,18 +764,31 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
                         (waves * 2 * kBlock * 64 * sizeof(double)) >> 20, hipGetErrorString(se));
     }
     b->fx_block_major = any_short;
+    const int stride = any_short ? (need + KLMI_BUFFER_SIZE + 15) & ~15 : 0;
+    const int tiles = any_short ? 0 : need / 8 + 3;
+    const size_t len = any_short ? (size_t)stride * n : (size_t)tiles * n * 8;
     DevBuf<double> grown;
-    hipError_t e = grown.alloc((size_t)stride * n);
+    hipError_t e = grown.alloc(len);
     if (e != hipSuccess)
         return fail(KLMI_E_MEMORY, "delay lines (%d samples x %d voices) do not fit: %s", need, b->n,
                     hipGetErrorString(e));
     // ordered on the context's stream like the kernels that read the lines (a caller's
     // non-blocking stream is not ordered after the null stream)
-    HIP_TRY(hipMemsetAsync(grown.p, 0, sizeof(double) * (size_t)stride * n, st));
-    if (b->fx_ring_cap > 0) {
+    HIP_TRY(hipMemsetAsync(grown.p, 0, sizeof(double) * len, st));
+    if (b->fx_ring_cap > 0 && any_short) {
         HIP_TRY(hipMemcpy2DAsync(grown.p, sizeof(double) * stride, b->fx_ring.p,
                                  sizeof(double) * b->fx_ring_stride,
                                  sizeof(double) * b->fx_ring_stride, n, hipMemcpyDeviceToDevice, st));
+    } else if (b->fx_ring_cap > 0) {
+        // the tiles of the last T_old - 1 time groups move to their places modulo the new T
+        const unsigned long long now = (unsigned long long)b->block_clock * (kBlock / 8);
+        const size_t row = n * 8;
+        for (int k = 1; k < b->fx_ring_tiles && (unsigned long long)k <= now; ++k) {
+            const unsigned long long g = now - (unsigned long long)k;
+            HIP_TRY(hipMemcpyAsync(grown.p + (size_t)(g % (unsigned)tiles) * row,
+                                   b->fx_ring.p + (size_t)(g % (unsigned)b->fx_ring_tiles) * row,
+                                   sizeof(double) * row, hipMemcpyDeviceToDevice, st));
+        }
     } else {
         HIP_TRY(hipMemsetAsync(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage), 0, sizeof(double) * n, st));
     }
@@ -762,6 +797,8 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
     std::swap(b->fx_ring.n, grown.n);
     b->fx_ring_backup.release();
     b->fx_ring_stride = stride;
+    b->fx_ring_tiles = tiles;
+    b->fx_ring_len = len;
     b->fx_ring_cap = need;
     b->fx_ring_dirty = false;
     return 0;
@@ -782,8 +819,14 @@ static int reset_changed_delay_lines(klmi_bank *b, int first, int count, const d
             run = i;
         if (!changed && run >= 0) {
             if (b->fx_ring_cap > 0) {
-                HIP_TRY(hipMemsetAsync(b->fx_ring.p + (size_t)(first + run) * b->fx_ring_stride, 0,
-                                       sizeof(double) * (size_t)(i - run) * b->fx_ring_stride, st));
+                if (b->fx_block_major)
+                    HIP_TRY(hipMemsetAsync(b->fx_ring.p + (size_t)(first + run) * b->fx_ring_stride, 0,
+                                           sizeof(double) * (size_t)(i - run) * b->fx_ring_stride, st));
+                else    // the voices' columns of every tile
+                    HIP_TRY(hipMemset2DAsync(b->fx_ring.p + (size_t)(first + run) * 8,
+                                             sizeof(double) * n * 8, 0,
+                                             sizeof(double) * (size_t)(i - run) * 8,
+                                             (size_t)b->fx_ring_tiles, st));
                 HIP_TRY(hipMemsetAsync(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage) + first + run, 0,
                                        sizeof(double) * (size_t)(i - run), st));
             }
@@ -1088,8 +1131,21 @@ extern "C" int klmi_bank_set_params(klmi_bank *b, int field, int first, int coun
                     return fail(KLMI_E_ARG, "klmi_bank_set_params: RingModulator Lfo wave id %g "
                                             "(sine, square, sawtooth, triangle are 0..3)", host[i]);
         }
-        if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0)
+        if (b->desc.fx[stage] == KLMI_FX_DELAY && k == 0) {
+            if (b->fx_ring_cap > 0) {
+                // the two line layouts do not convert into each other once the lines are in
+                // use: refused HERE, before anything is touched, so the bank stays renderable
+                int longest = 0;
+                bool any_short = false;
+                delay_line_shape(b, first, count, host, &longest, &any_short);
+                if (any_short != b->fx_block_major)
+                    return fail(KLMI_E_STATE, "Delay times shorter than one buffer (%d samples) have "
+                                              "to be set before the bank's first render, for all "
+                                              "voices at once, and cannot be left again later "
+                                              "(nothing was changed)", KLMI_BUFFER_SIZE);
+            }
             TRY(reset_changed_delay_lines(b, first, count, host));
+        }
         std::copy(host, host + count,
                   b->fx_raw.begin() + ((size_t)stage * KLMI_FX_PARAMS + k) * b->n + first);
         return upload_fx(b, stage, first, count);
@@ -1746,7 +1802,7 @@ static int render_preview(klmi_bank *b, int first, int count, int n_blocks, void
     TRY(ensure_fx_ring(b));
     hipStream_t st = b->ctx->stream;
     const size_t n = (size_t)b->n;
-    const size_t ring_len = (size_t)b->fx_ring_stride * n;
+    const size_t ring_len = b->fx_ring_len;
     if (ring_len) {  // the delay lines are state too
         if (ring_len * sizeof(double) > ((size_t)1 << 30))
             return fail(KLMI_E_STATE, "klmi_bank_render_voices: previews of banks with more than "

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
     }
     int delay_pos = 0, delay_len = 1;
     double delay_fb = 0., delay_dw = 0.;
+    // block-major layout only (a line shorter than a buffer): the voice's RingBuffer array
     double *delay_line = bk.fx_ring + (size_t)v * bk.fx_ring_stride;
     if (delay_stage >= 0) {
         const double *par = bk.fx_par + (size_t)(delay_stage * kFxSlots) * n + v;
@@ -371,6 +372,9 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
 
     for (int b = 0; b < n_blocks; ++b) {
         const uint32_t abs_block = clock_base + (uint32_t)b;
+        // time tile of the block's first sample (long delay lines: bank_kernels.h delay_read8)
+        const int block_tile = (HAS_FX && delay_stage >= 0 && bk.fx_ring_tiles > 0)
+                                   ? delay_tile_of_block(abs_block, bk.fx_ring_tiles) : 0;
         // Voice.active (voices.py:45-53) is asked before the notes are processed
         const bool was_active = !has_env || es.stage != 0;
         bool had_note = false;
@@ -708,37 +712,18 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                             for (int i8 = half; i8 < half + SUB; i8 += G) {
                                 double x[G];
                                 load_x(i8 - half, x);
-                                // The voice's own line is contiguous (positions differ from voice to
-                                // voice, so nothing coalesces ACROSS lanes: a lane's 8 slots = 64 B of
-                                // one cache line).  Slots [len, len+8) mirror slots [0, 8), so the 8
-                                // reads never wrap; length >= a buffer, so they never see this
-                                // block's writes.
-                                int idx0 = delay_pos + c * CH + i8;
-                                idx0 = idx0 >= delay_len ? idx0 - delay_len : idx0;
-                                double *line = delay_line + idx0;
-                                double w[G];
+                                // lines tiled by absolute time (bank_kernels.h delay_read8);
+                                // length >= a buffer, so the 8 reads never see this block's writes
+                                int ttile = block_tile + ((c * CH + i8) >> 3);
+                                ttile = ttile >= bk.fx_ring_tiles ? ttile - bk.fx_ring_tiles : ttile;
+                                double old[G], w[G];
+                                delay_read8(bk.fx_ring, n, bk.fx_ring_tiles, ttile, delay_len >> 3,
+                                            delay_len & 7, v, old);
 #pragma unroll
-                                for (int j = 0; j < G; j += 2) {
-                                    const Double2U old = reinterpret_cast<const Double2U *>(line)[j >> 1];
-                                    w[j] = x[j] + delay_fb * old.a;
-                                    w[j + 1] = x[j + 1] + delay_fb * old.b;
-                                }
-                                if (live) {
-#pragma unroll
-                                    for (int j = 0; j < G; j += 2)
-                                        reinterpret_cast<Double2U *>(line)[j >> 1] = Double2U{w[j], w[j + 1]};
-                                    // keep slots and mirror in step where the 8 touch either end
-                                    if (idx0 < 8 || idx0 + G > delay_len) {
-#pragma unroll
-                                        for (int j = 0; j < G; ++j) {
-                                            const int idx = idx0 + j;
-                                            if (idx >= delay_len)
-                                                delay_line[idx - delay_len] = w[j];
-                                            else if (idx < 8)
-                                                delay_line[idx + delay_len] = w[j];
-                                        }
-                                    }
-                                }
+                                for (int j = 0; j < G; ++j)
+                                    w[j] = x[j] + delay_fb * old[j];
+                                if (live)
+                                    delay_write8(bk.fx_ring, n, ttile, v, w);
 #pragma unroll
                                 for (int j = 0; j < G; ++j)
                                     x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];

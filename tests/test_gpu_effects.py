@@ -248,13 +248,24 @@ def test_short_and_long_delay_lines_in_one_bank_vs_oracle(hip, ctx, oracle, ster
     np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
     hb.close()
     if not stereo:
+        # a layout switch after the first render is refused where it is asked for, and the
+        # refused call changes nothing: the bank renders on as if it had not been made
         late = saw_bank(hip, ctx, [(hip.FX_DELAY, .01, .5, .5)], n=2)
-        late.render(1)
-        late.set(hip.F_FX(0, 0), [.001, .01])
+        twin = saw_bank(hip, ctx, [(hip.FX_DELAY, .01, .5, .5)], n=2)
+        np.testing.assert_array_equal(late.render(2), twin.render(2))
         with pytest.raises(hip.NativeError) as e:
-            late.render(1)
-        assert 'before the bank' in str(e.value)
+            late.set(hip.F_FX(0, 0), [.001, .01])
+        assert e.value.code == hip.E_STATE and 'before the bank' in str(e.value)
+        np.testing.assert_array_equal(late.get_state(hip.F_FX_STATE(0, 0)),
+                                      twin.get_state(hip.F_FX_STATE(0, 0)))
+        np.testing.assert_array_equal(late.render(3), twin.render(3))
+        # a longer time is fine: the voice's line starts again empty, the other keeps its own
+        late.set(hip.F_FX(0, 0), [.02], first=1)
+        twin.set(hip.F_FX(0, 0), [.02], first=1)
+        a, b = late.render_voices(4, f64=True), twin.render_voices(4, f64=True)
+        np.testing.assert_array_equal(a, b)
         late.close()
+        twin.close()
 
 
 def test_crusher_and_ring_modulator_vs_oracle_many_voices(hip, ctx, oracle):

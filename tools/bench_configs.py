@@ -123,7 +123,14 @@ def config3_general(ctx, label, **bank_kw):
         if kind == native.FX_TREMOLO:
             bank.set(native.F_FX(s, 0), 1. + 8. * rng.random(n))
         elif kind == native.FX_DELAY:
-            bank.set(native.F_FX(s, 0), .006 + .01 * rng.random(n))
+            mode = os.environ.get('KLANG_BENCH_DELAY', 'random')
+            if mode == 'equal':       # one delay time for the whole bank (the usual patch)
+                bank.set(native.F_FX(s, 0), np.full(n, .0113))
+            elif mode == 'few':       # a handful of times, as a patch with note-value delays has
+                bank.set(native.F_FX(s, 0), np.repeat([.0075, .009, .0113, .015], n // 4 + 1)[:n])
+            else:                     # worst case: every voice its own time
+                bank.set(native.F_FX(s, 0), .006 + .01 * rng.random(n))
+            label += ' [%s times]' % mode
         elif kind == native.FX_GAIN:
             bank.set(native.F_FX(s, 0), rng.random(n))
     queue(bank, ev, n_blocks, 5)
