@@ -242,47 +242,55 @@ __device__ __forceinline__ void flush_chunk(typename TileTraits<MODE>::T *tile, 
 }
 
 // ---- Delay lines tiled by absolute time (effects.py:136-174, ring_buffer.py:62-109) -----------
-// tiles[(t / 8) % T][voice][t % 8]: the sample a voice wrote at absolute time t.  The delayed
+// tiles[(t / TS) % T][voice][t % TS] (TS = kDelayTile samples): what a voice wrote at time t.  The delayed
 // sample of time t is the one written at t - length (zero before the line's start: the tiles
 // start as zeros and a voice's column is cleared when its length changes), so a voice needs
 // no position in memory.  A wavefront's eight new samples are ONE contiguous 4 KiB piece of a
 // tile row; its eight delayed samples lie in two neighbouring tile rows, contiguous across the
-// lanes whenever the voices' delay times agree.  T >= longest / 8 + 3: the tile being written
+// lanes whenever the voices' delay times agree.  T >= longest / TS + 3: the tile being written
 // is never one being read.
-struct DelayTap {
-    const double *cur_base;   // (tile holding t0 - length) - r: element j >= r of the group is cur_base[j]
-    const double *prev_base;  // (the tile before it) + 8 - r:   element j <  r is prev_base[j]
-    int r;
-};
+#ifndef KLMI_DELAY_TILE
+#define KLMI_DELAY_TILE 8
+#endif
+constexpr int kDelayTile = KLMI_DELAY_TILE;   // samples of one voice per time tile (8 or 16)
+static_assert(kDelayTile == 8 || kDelayTile == 16, "a group of 8 samples is a tile or half of one");
 
-// The eight samples written `length` = 8 q + r samples before group `g` (tile index, already
-// reduced modulo T) of voice v; q < T - 2.
-__device__ __forceinline__ void delay_read8(const double *tiles, size_t n, int T, int g, int q, int r,
-                                            int v, double (&old)[8])
+// The eight samples written `length` samples before the group that starts at sample `s8` * 8
+// of tile `g` (tile index already reduced modulo T) of voice v; length / kDelayTile < T - 2.
+__device__ __forceinline__ void delay_read8(const double *tiles, size_t n, int T, int g, int s8,
+                                            int length, int v, double (&old)[8])
 {
-    int tc = g - q;
-    tc = tc < 0 ? tc + T : tc;
-    int tp = tc - 1;
-    tp = tp < 0 ? tp + T : tp;
-    const double *pc = tiles + ((size_t)tc * n + (size_t)v) * 8 - r;
-    const double *pp = tiles + ((size_t)tp * n + (size_t)v) * 8 + 8 - r;
+    constexpr int TS = kDelayTile;
+    // first delayed sample: TS * (g - q) + 8 * s8 - r, with length = TS * q + r
+    const int q = length / TS, r = length % TS;
+    int off = 8 * s8 - r;
+    int t0 = g - q;
+    if (off < 0)
+        off += TS, t0 -= 1;
+    t0 = t0 < 0 ? t0 + T : t0;
+    int t1 = t0 + 1;
+    t1 = t1 >= T ? t1 - T : t1;
+    const double *p0 = tiles + ((size_t)t0 * n + (size_t)v) * TS + off;         // elements j < TS - off
+    const double *p1 = tiles + ((size_t)t1 * n + (size_t)v) * TS + off - TS;    // the others
+    const int split = TS - off;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        old[j] = (j >= r ? pc : pp)[j];
+        old[j] = (j < split ? p0 : p1)[j];
 }
 
-__device__ __forceinline__ void delay_write8(double *tiles, size_t n, int g, int v, const double (&w)[8])
+__device__ __forceinline__ void delay_write8(double *tiles, size_t n, int g, int s8, int v,
+                                             const double (&w)[8])
 {
-    double2 *dst = reinterpret_cast<double2 *>(tiles + ((size_t)g * n + (size_t)v) * 8);
+    double2 *dst = reinterpret_cast<double2 *>(tiles + ((size_t)g * n + (size_t)v) * kDelayTile + 8 * s8);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         dst[j] = make_double2(w[2 * j], w[2 * j + 1]);
 }
 
-// tile index of the first sample of absolute block `clock`: (clock * 32) % T
+// tile index of the first sample of absolute block `clock`: (clock * tiles per block) % T
 __device__ __forceinline__ int delay_tile_of_block(uint32_t clock, int T)
 {
-    return (int)(((unsigned long long)clock * (kBlock / 8)) % (unsigned)T);
+    return (int)(((unsigned long long)clock * (kBlock / kDelayTile)) % (unsigned)T);
 }
 
 // Lfo(shape=1) | Filter.frequency, once per block (oscillators.py:175-181,

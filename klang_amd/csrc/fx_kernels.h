@@ -131,14 +131,13 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
     const double trem_floor = 1. - trem_depth;
     // Delay (effects.py:136-174): lines tiled by absolute time (bank_kernels.h delay_read8);
     // the position is carried only as the state the reference's RingBuffer would report
-    int delay_pos = 0, delay_len = 1, delay_q = 0, delay_r = 0;
+    int delay_pos = 0, delay_len = 1;
     double delay_fb = 0., delay_dw = 0.;
     const int delay_tiles = bk.fx_ring_tiles;
     if constexpr (DELAY >= 0) {
         const double *par = bk.fx_par + (size_t)((FIRST_STAGE + DELAY) * kFxSlots) * n + v;
         delay_pos = (int)bk.fx_state[(size_t)(2 * (FIRST_STAGE + DELAY)) * n + v];
         delay_len = (int)par[0];
-        delay_q = delay_len >> 3, delay_r = delay_len & 7;
         delay_fb = par[n], delay_dw = par[2 * n];
     }
     const double delay_dry = 1. - delay_dw;
@@ -280,11 +279,12 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
                 const Time8 tt = times[i8 >> 3];
                 // the Delay's eight delayed samples, asked for first
                 double old[G] = {};
-                int ttile = 0;   // wave-uniform: the time tile of this group
+                int ttile = 0, tsub = 0;   // wave-uniform: time tile of this group, group in the tile
                 if constexpr (DELAY >= 0) {
-                    ttile = block_tile + ((c * CH + i8) >> 3);
+                    ttile = block_tile + (c * CH + i8) / kDelayTile;
                     ttile = ttile >= delay_tiles ? ttile - delay_tiles : ttile;
-                    delay_read8(bk.fx_ring, n, delay_tiles, ttile, delay_q, delay_r, v, old);
+                    tsub = ((c * CH + i8) % kDelayTile) >> 3;
+                    delay_read8(bk.fx_ring, n, delay_tiles, ttile, tsub, delay_len, v, old);
                 }
 
                 double osc[G];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
                         for (int j = 0; j < G; ++j)
                             w[j] = y[j] + delay_fb * old[j];
                         if (live)
-                            delay_write8(bk.fx_ring, n, ttile, v, w);
+                            delay_write8(bk.fx_ring, n, ttile, tsub, v, w);
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             y[j] = delay_dry * y[j] + delay_dw * w[j];

@@ -765,8 +765,8 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
     }
     b->fx_block_major = any_short;
     const int stride = any_short ? (need + KLMI_BUFFER_SIZE + 15) & ~15 : 0;
-    const int tiles = any_short ? 0 : need / 8 + 3;
-    const size_t len = any_short ? (size_t)stride * n : (size_t)tiles * n * 8;
+    const int tiles = any_short ? 0 : need / kDelayTile + 3;
+    const size_t len = any_short ? (size_t)stride * n : (size_t)tiles * n * kDelayTile;
     DevBuf<double> grown;
     hipError_t e = grown.alloc(len);
     if (e != hipSuccess)
@@ -781,8 +781,8 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
                                  sizeof(double) * b->fx_ring_stride, n, hipMemcpyDeviceToDevice, st));
     } else if (b->fx_ring_cap > 0) {
         // the tiles of the last T_old - 1 time groups move to their places modulo the new T
-        const unsigned long long now = (unsigned long long)b->block_clock * (kBlock / 8);
-        const size_t row = n * 8;
+        const unsigned long long now = (unsigned long long)b->block_clock * (kBlock / kDelayTile);
+        const size_t row = n * kDelayTile;
         for (int k = 1; k < b->fx_ring_tiles && (unsigned long long)k <= now; ++k) {
             const unsigned long long g = now - (unsigned long long)k;
             HIP_TRY(hipMemcpyAsync(grown.p + (size_t)(g % (unsigned)tiles) * row,
@@ -823,9 +823,9 @@ static int reset_changed_delay_lines(klmi_bank *b, int first, int count, const d
                     HIP_TRY(hipMemsetAsync(b->fx_ring.p + (size_t)(first + run) * b->fx_ring_stride, 0,
                                            sizeof(double) * (size_t)(i - run) * b->fx_ring_stride, st));
                 else    // the voices' columns of every tile
-                    HIP_TRY(hipMemset2DAsync(b->fx_ring.p + (size_t)(first + run) * 8,
-                                             sizeof(double) * n * 8, 0,
-                                             sizeof(double) * (size_t)(i - run) * 8,
+                    HIP_TRY(hipMemset2DAsync(b->fx_ring.p + (size_t)(first + run) * kDelayTile,
+                                             sizeof(double) * n * kDelayTile, 0,
+                                             sizeof(double) * (size_t)(i - run) * kDelayTile,
                                              (size_t)b->fx_ring_tiles, st));
                 HIP_TRY(hipMemsetAsync(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage) + first + run, 0,
                                        sizeof(double) * (size_t)(i - run), st));

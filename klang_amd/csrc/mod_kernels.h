@@ -714,16 +714,16 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                                 load_x(i8 - half, x);
                                 // lines tiled by absolute time (bank_kernels.h delay_read8);
                                 // length >= a buffer, so the 8 reads never see this block's writes
-                                int ttile = block_tile + ((c * CH + i8) >> 3);
+                                int ttile = block_tile + (c * CH + i8) / kDelayTile;
                                 ttile = ttile >= bk.fx_ring_tiles ? ttile - bk.fx_ring_tiles : ttile;
+                                const int tsub = ((c * CH + i8) % kDelayTile) >> 3;
                                 double old[G], w[G];
-                                delay_read8(bk.fx_ring, n, bk.fx_ring_tiles, ttile, delay_len >> 3,
-                                            delay_len & 7, v, old);
+                                delay_read8(bk.fx_ring, n, bk.fx_ring_tiles, ttile, tsub, delay_len, v, old);
 #pragma unroll
                                 for (int j = 0; j < G; ++j)
                                     w[j] = x[j] + delay_fb * old[j];
                                 if (live)
-                                    delay_write8(bk.fx_ring, n, ttile, v, w);
+                                    delay_write8(bk.fx_ring, n, ttile, tsub, v, w);
 #pragma unroll
                                 for (int j = 0; j < G; ++j)
                                     x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
