@@ -296,17 +296,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if rehearse:
-        from klang_amd import sharding
-        dist.init_process_group('gloo')
-
-        def reduce_via_host(bus, n_total, world_size, dst=0, group=None, always=False):
-            host = bus.cpu()
-            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
-            bus.copy_(host)
-            if n_total > 1:
-                bus /= float(n_total)
-            return bus
-        sharding.reduce_bus = reduce_via_host
+        dist.init_process_group('gloo')     # sharding.reduce_bus hops through the host then
     elif world > 1:
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 

@@ -77,7 +77,14 @@ def reduce_bus(bus, n_total, world_size, dst=0, group=None, always=False):
     tensors (gloo).  Returns the bus (meaningful on `dst` only).  `always` issues the
     collective in a world of one rank too (the same call path on a one-GPU box)."""
     if world_size > 1 or always:
-        dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if bus.is_cuda and dist.get_backend(group) == 'gloo':
+            # a gloo group over GPU buses (several ranks sharing ONE GPU, where RCCL refuses to
+            # run: rehearsals and tests): the reduce goes through host copies
+            host = bus.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            bus.copy_(host)
+        else:
+            dist.reduce(bus, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if n_total > 1:
         bus /= float(n_total)
     return bus

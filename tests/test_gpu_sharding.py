@@ -230,3 +230,52 @@ def test_sharding_needs_something_to_shard(hip):
         run_klang(Oscillator(440.) | Dac(), offline=True, duration=.1, shard=(0, 2))
     with pytest.raises(KlangError, match='offline'):
         run_klang(_api_patch(4), shard=(0, 2))
+
+
+def _two_process_worker(rank, world, port, out_path, n_voices, dur):
+    """One rank of a REAL two-process run on the one GPU of the box: gloo group (RCCL refuses two
+    ranks on one device), so the HIP bus of each process meets the collective through host
+    copies (sharding.reduce_bus); everything else is the production path of run_klang."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from klang_amd.klang import run_klang
+    from tests.test_gpu_sharding import _api_patch
+    frames = run_klang(_api_patch(n_voices), offline=True, duration=dur, fadeout=.02,
+                       filepath=out_path + '.wav')       # shard: what the process group says
+    if rank == 0:
+        np.save(out_path, np.concatenate(frames))
+    else:
+        assert frames == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_through_run_klang(hip, tmp_path):
+    """Two processes, one per rank, both on device 0: each builds the same 90-voice patch, calls
+    run_klang with no shard argument (the process group decides), keeps its half of the voices,
+    and the partial HIP buses are summed by a real collective.  Rank 0's frames and WAV file
+    against the unsharded patch rendered here."""
+    import wave
+
+    import torch.multiprocessing as mp
+    from klang_amd.klang import run_klang
+    dur = 48 * B / 44100. + 1e-9
+    out = str(tmp_path / 'frames.npy')
+    mp.get_context('spawn')
+    mp.spawn(_two_process_worker, args=(2, _free_port(), out, 90, dur), nprocs=2, join=True)
+    got = np.load(out)
+    want = np.concatenate(run_klang(_api_patch(90), offline=True, duration=dur, fadeout=.02,
+                                    filepath=str(tmp_path / 'plain.wav')))
+    assert got.shape == want.shape == (48 * B, 1) and np.abs(want).max() > 1e-2
+    assert report('run_klang, 2 processes on one GPU vs one bank', np.abs(got - want).max()) <= 1e-6
+    with wave.open(out + '.wav') as a, wave.open(str(tmp_path / 'plain.wav')) as b:
+        pa = np.frombuffer(a.readframes(a.getnframes()), dtype=np.int16).astype(int)
+        pb = np.frombuffer(b.readframes(b.getnframes()), dtype=np.int16).astype(int)
+    assert pa.shape == pb.shape and np.abs(pa - pb).max() <= 2      # int16 steps of the normalised samples
