@@ -1,5 +1,6 @@
 // fx_kernels.h -- the voice kernel for chains with a short, common effect program behind the
-// [Filter]: Tremolo, Delay and Gain stages (klang/audio/effects.py:58-70, 100-174), the program
+// [Filter]: Tremolo, Delay and element-wise stages (Gain, Transformer, TanhDistortion,
+// OctaveDistortion, Subsampler, Bitcrusher: klang/audio/effects.py:58-174, 388-483, 522-561), the program
 // known at compile time (gfx950).
 //
 // voice_mod_kernel (mod_kernels.h) interprets ANY stage program, stage-major over an LDS strip:
@@ -29,6 +30,11 @@ constexpr uint32_t fx_program(int a, int b = 0, int c = 0)
     return (uint32_t)a | ((uint32_t)b << 4) | ((uint32_t)c << 8);
 }
 constexpr int fx_program_kind(uint32_t prog, int s) { return (int)((prog >> (4 * s)) & 15u); }
+// Slot kind of a program that stands for ANY element-wise stage (Gain, Transformer,
+// TanhDistortion, OctaveDistortion, Subsampler, Bitcrusher), its kind chosen at run time by a
+// scalar jump; FX_GAIN slots stay plain multiplies (the Tremolo / Delay / Gain programs of the
+// reference's patches lose nothing to the generality)
+constexpr int FX_ELEM = 15;
 constexpr int fx_program_length(uint32_t prog)
 {
     return fx_program_kind(prog, 2) ? 3 : fx_program_kind(prog, 1) ? 2 : fx_program_kind(prog, 0) ? 1 : 0;
@@ -142,12 +148,19 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
     }
     const double delay_dry = 1. - delay_dw;
     // Gain stages (effects.py:58-70): one parameter each
-    double gain_par[NSTAGE];
+    // Element-wise stages (the FX_ELEM slot of a program stands for any of them: Gain,
+    // Transformer, TanhDistortion, OctaveDistortion, Subsampler, Bitcrusher -- effects.py:58-70,
+    // 388-483, 522-561): their kind is a bank constant, chosen by a scalar jump per group
+    double gain_par[NSTAGE], gain_par1[NSTAGE];
+    int elem_kind[NSTAGE];
 #pragma unroll
-    for (int s = 0; s < NSTAGE; ++s)
-        gain_par[s] = fx_program_kind(PROG, s) == FX_GAIN
-                          ? bk.fx_par[(size_t)((FIRST_STAGE + s) * kFxSlots) * n + v]
-                          : 0.;
+    for (int s = 0; s < NSTAGE; ++s) {
+        const bool elem = fx_program_kind(PROG, s) == FX_GAIN || fx_program_kind(PROG, s) == FX_ELEM;
+        gain_par[s] = elem ? bk.fx_par[(size_t)((FIRST_STAGE + s) * kFxSlots) * n + v] : 0.;
+        gain_par1[s] = elem ? bk.fx_par[(size_t)((FIRST_STAGE + s) * kFxSlots + 1) * n + v] : 0.;
+        elem_kind[s] = elem ? (int)bk.fx_kind[FIRST_STAGE + s] : 0;
+    }
+    double held = 0.;   // Subsampler: the sample being repeated (at most one per chain)
 
     double gl = 0., gr = 0.;
     if (MIX) {
@@ -379,6 +392,48 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             y[j] = gain_par[s] * y[j];
+                    } else if (kind == FX_ELEM) {      // an element-wise stage (wave-uniform kind)
+                        const double p0 = gain_par[s];
+                        switch (elem_kind[s]) {
+                        case FX_TRANSFORM:              // effects.py:558-561
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                y[j] = p0 * y[j] + gain_par1[s];
+                            break;
+                        case FX_TANH:                   // effects.py:480-483
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                y[j] = tanh(p0 * y[j]);
+                            break;
+                        case FX_OCTAVE:                 // effects.py:460-462
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                y[j] = 2. * (y[j] * y[j]) - 1.;
+                            break;
+                        case FX_SUBSAMPLE: {            // effects.py:400-415: np.repeat(x[::skip], skip)
+                            const int mask = (int)p0 - 1;
+#pragma unroll
+                            for (int j = 0; j < G; ++j) {
+                                held = ((c * CH + i8 + j) & mask) == 0 ? y[j] : held;
+                                y[j] = held;
+                            }
+                            break;
+                        }
+                        case FX_BITCRUSH: {             // effects.py:434-447, wavfile.py:14-30
+                            const int bits = (int)p0;
+#pragma unroll
+                            for (int j = 0; j < G; ++j) {
+                                const int q = (int)(short)(int)(32767. * y[j]);  // astype(int16)
+                                y[j] = (double)(int)(short)((q >> bits) << bits) * (1. / 32768.);
+                            }
+                            break;
+                        }
+                        default:                        // Gain, effects.py:67-70
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                y[j] = p0 * y[j];
+                            break;
+                        }
                     } else if (kind == FX_DELAY) {     // effects.py:166-174: wet = new + feedback * delayed
                         double w[G];
 #pragma unroll

@@ -118,7 +118,9 @@ def test_effect_chains_vs_oracle_many_voices(hip, ctx, oracle):
     np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0)
 
 
-PROGRAMS = ['T', 'D', 'G', 'TG', 'DG', 'TD', 'DT']
+# T Tremolo, D Delay; the element-wise kinds share one compiled slot: G Gain, X Transformer,
+# O OctaveDistortion, B Bitcrusher, S Subsampler
+PROGRAMS = ['T', 'D', 'G', 'TG', 'DG', 'TD', 'DT', 'X', 'OG', 'GBS', 'BT', 'SD', 'XDO', 'BS']
 
 
 @pytest.mark.parametrize('program,has_filter,kernel',
@@ -126,8 +128,9 @@ PROGRAMS = ['T', 'D', 'G', 'TG', 'DG', 'TD', 'DT']
                          + [('TD', True, 'general'), ('DG', False, 'general')])
 def test_compiled_effect_programs_vs_oracle_bit_exact(hip, ctx, oracle, monkeypatch, program,
                                                       has_filter, kernel):
-    """The Tremolo / Delay / Gain programs voice_fx_kernel is compiled for (fx_tu.hip), behind
-    the Filter or without one: 64 * 9 + 20 voices with notes, per-voice stage parameters, wave
+    """The Tremolo / Delay / element-wise programs voice_fx_kernel is compiled for (fx_tu.hip:
+    Gain, Transformer, OctaveDistortion, Bitcrusher and Subsampler share the element-wise slot),
+    behind the Filter or without one: 64 * 9 + 20 voices with notes, per-voice stage parameters, wave
     functions that differ from wavefront to wavefront (one wavefront mixed), some negative
     Tremolo rates (the exact remainder) -- float64 streams, stage state and delay lines
     positions equal the oracle's bit for bit, the mix over split launches within 1e-6.
@@ -145,7 +148,11 @@ def test_compiled_effect_programs_vs_oracle_bit_exact(hip, ctx, oracle, monkeypa
     rate[300:310] = -rate[300:310]
     make = {'T': lambda: (hip.FX_TREMOLO, rate, rng.random(n), rng.random(n), .1 + .8 * rng.random(n)),
             'D': lambda: (hip.FX_DELAY, .006 + .05 * rng.random(n), .9 * rng.random(n), rng.random(n)),
-            'G': lambda: (hip.FX_GAIN, 1.5 * rng.random(n))}
+            'G': lambda: (hip.FX_GAIN, 1.5 * rng.random(n)),
+            'X': lambda: (hip.FX_TRANSFORM, .5 + rng.random(n), rng.random(n) - .5),
+            'O': lambda: (hip.FX_OCTAVE,),
+            'B': lambda: (hip.FX_BITCRUSH, rng.integers(0, 16, n)),
+            'S': lambda: (hip.FX_SUBSAMPLE, 2 ** rng.integers(1, 8, n))}
     stages = ([(hip.FX_FILTER,)] if has_filter else []) + [make[k]() for k in program]
     table, grid = library_table(hip)
     from tests.helpers import oracle_bank_from_patch

@@ -133,6 +133,10 @@ def config3_general(ctx, label, **bank_kw):
             label += ' [%s times]' % mode
         elif kind == native.FX_GAIN:
             bank.set(native.F_FX(s, 0), rng.random(n))
+        elif kind == native.FX_BITCRUSH:
+            bank.set(native.F_FX(s, 0), rng.integers(4, 12, n).astype(float))
+        elif kind == native.FX_SUBSAMPLE:
+            bank.set(native.F_FX(s, 0), (2 ** rng.integers(1, 4, n)).astype(float))
     queue(bank, ev, n_blocks, 5)
     best, med = timed(lambda: bank.render(n_blocks))
     ms, launches = bank.last_kernel_ms()
@@ -238,6 +242,10 @@ def main():
         elif w == '3delay':
             r = config3_general(ctx, 'Filter -> Delay(6-16 ms) -> Gain',
                                 effects=[native.FX_FILTER, native.FX_DELAY, native.FX_GAIN])
+        elif w == '3lofi':
+            r = config3_general(ctx, 'Filter -> Gain -> Bitcrusher -> Subsampler',
+                                effects=[native.FX_FILTER, native.FX_GAIN, native.FX_BITCRUSH,
+                                         native.FX_SUBSAMPLE])
         elif w == 'synth':
             r = config_synth(ctx)
         elif w == '4big':
