@@ -176,8 +176,8 @@ def test_float32_ring_storage_measured(hip, ctx, oracle, golden):
     assert out_err <= 2e-6 and ring_err <= 5e-6
 
 
-@pytest.mark.parametrize('stereo', [False, True])
-def test_fused_voice_reverb_kernel_equals_the_two_kernel_path(hip, ctx, monkeypatch, stereo):
+@pytest.mark.parametrize('stereo,has_env', [(False, True), (True, True), (False, False)])
+def test_fused_voice_reverb_kernel_equals_the_two_kernel_path(hip, ctx, monkeypatch, stereo, has_env):
     """reverb_voice_kernel (dry voice made inside the reverb wave, 1 / 2 / 4 voices per wave)
     against the voice kernel + reverb_kernel pair on a random bank with float64 rings: delay
     lines, ring positions and every voice state bit for bit, the mix to the float32 rounding of
@@ -195,6 +195,7 @@ def test_fused_voice_reverb_kernel_equals_the_two_kernel_path(hip, ctx, monkeypa
     patch['retrigger'] = rng.random(n) < .5
     patch['gain'] = .5 + rng.random(n)
     patch['stereo'] = stereo
+    patch['has_env'] = has_env          # False: plain oscillators in front of the Reverbs
     patch['pan'] = rng.uniform(-1., 1., n)
     ev = patch.events.copy()
     ev['frequency'] *= 1. + .5 * rng.random(len(ev))
