@@ -287,6 +287,20 @@ __device__ __forceinline__ void delay_write8(double *tiles, size_t n, int g, int
         dst[j] = make_double2(w[2 * j], w[2 * j + 1]);
 }
 
+// a whole tile of 16 samples (kDelayTile == 16): the group before this one (`lo`) and this one
+// (`hi`) as ONE 128-byte piece per voice -- a full cache line, never half of one
+__device__ __forceinline__ void delay_write16(double *tiles, size_t n, int g, int v,
+                                              const double (&lo)[8], const double (&hi)[8])
+{
+    double2 *dst = reinterpret_cast<double2 *>(tiles + ((size_t)g * n + (size_t)v) * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        dst[j] = make_double2(lo[2 * j], lo[2 * j + 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        dst[4 + j] = make_double2(hi[2 * j], hi[2 * j + 1]);
+}
+
 // tile index of the first sample of absolute block `clock`: (clock * tiles per block) % T
 __device__ __forceinline__ int delay_tile_of_block(uint32_t clock, int T)
 {

@@ -161,6 +161,7 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
         elem_kind[s] = elem ? (int)bk.fx_kind[FIRST_STAGE + s] : 0;
     }
     double held = 0.;   // Subsampler: the sample being repeated (at most one per chain)
+    double wstash[G] = {};   // Delay, 16-sample tiles: the first half of the tile being written
 
     double gl = 0., gr = 0.;
     if (MIX) {
@@ -439,8 +440,18 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             w[j] = y[j] + delay_fb * old[j];
-                        if (live)
+                        if constexpr (kDelayTile == 16) {
+                            // the first half of a tile waits for the second (wave-uniform)
+                            if (tsub == 0) {
+#pragma unroll
+                                for (int j = 0; j < G; ++j)
+                                    wstash[j] = w[j];
+                            } else if (live) {
+                                delay_write16(bk.fx_ring, n, ttile, v, wstash, w);
+                            }
+                        } else if (live) {
                             delay_write8(bk.fx_ring, n, ttile, tsub, v, w);
+                        }
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             y[j] = delay_dry * y[j] + delay_dw * w[j];

@@ -709,6 +709,8 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                         }
                         case FX_DELAY: {    // effects.py:166-174 (the blend reads the window after
                                             // the write: wet = new + feedback * delayed)
+                            double wstash[G] = {};   // 16-sample tiles: first half of the tile
+                            static_assert(SUB % 16 == 0, "whole tiles per strip");
                             for (int i8 = half; i8 < half + SUB; i8 += G) {
                                 double x[G];
                                 load_x(i8 - half, x);
@@ -722,8 +724,17 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
 #pragma unroll
                                 for (int j = 0; j < G; ++j)
                                     w[j] = x[j] + delay_fb * old[j];
-                                if (live)
+                                if constexpr (kDelayTile == 16) {
+                                    if (tsub == 0) {
+#pragma unroll
+                                        for (int j = 0; j < G; ++j)
+                                            wstash[j] = w[j];
+                                    } else if (live) {
+                                        delay_write16(bk.fx_ring, n, ttile, v, wstash, w);
+                                    }
+                                } else if (live) {
                                     delay_write8(bk.fx_ring, n, ttile, tsub, v, w);
+                                }
 #pragma unroll
                                 for (int j = 0; j < G; ++j)
                                     x[j] = (1. - delay_dw) * x[j] + delay_dw * w[j];
