@@ -11,6 +11,7 @@
 #pragma once
 #include "dsp_device.h"
 #include <type_traits>
+#include <utility>
 
 namespace klmi {
 
@@ -253,6 +254,25 @@ __device__ __forceinline__ void flush_chunk(typename TileTraits<MODE>::T *tile, 
 #define KLMI_DELAY_TILE 8
 #endif
 constexpr int kDelayTile = KLMI_DELAY_TILE;   // samples of one voice per time tile (8 or 16)
+// Which tiles are neighbours in memory.  Wave-major (1; measured slower, kept as a build option): the T tiles of one wavefront's
+// 64 voices are one contiguous region, tiles[voice / 64][(t / TS) % T][voice % 64][TS] -- a
+// wavefront whose voices have 64 different delay times still reads inside its own T * 4 KiB
+// (one or two pages of the address translation, a few DRAM rows) instead of 64 tile rows that lie
+// n * 64 bytes apart.  0 (the default): tiles[(t / TS) % T][voice][TS], a tile row over all voices.
+#ifndef KLMI_DELAY_WAVE_MAJOR
+#define KLMI_DELAY_WAVE_MAJOR 0
+#endif
+// first element of tile t (already reduced modulo T) of voice v, and the allocation's length
+__host__ __device__ __forceinline__ size_t delay_tile_at(size_t n, int T, int t, int v)
+{
+    if (KLMI_DELAY_WAVE_MAJOR)
+        return ((((size_t)v >> 6) * (size_t)T + (size_t)t) * 64 + ((size_t)v & 63)) * kDelayTile;
+    return ((size_t)t * n + (size_t)v) * kDelayTile;
+}
+__host__ __device__ __forceinline__ size_t delay_tiles_len(size_t n, int T)
+{
+    return (KLMI_DELAY_WAVE_MAJOR ? (n + 63) / 64 * 64 : n) * (size_t)T * kDelayTile;
+}
 static_assert(kDelayTile == 8 || kDelayTile == 16, "a group of 8 samples is a tile or half of one");
 
 // The eight samples written `length` samples before the group that starts at sample `s8` * 8
@@ -270,18 +290,18 @@ __device__ __forceinline__ void delay_read8(const double *tiles, size_t n, int T
     t0 = t0 < 0 ? t0 + T : t0;
     int t1 = t0 + 1;
     t1 = t1 >= T ? t1 - T : t1;
-    const double *p0 = tiles + ((size_t)t0 * n + (size_t)v) * TS + off;         // elements j < TS - off
-    const double *p1 = tiles + ((size_t)t1 * n + (size_t)v) * TS + off - TS;    // the others
+    const double *p0 = tiles + delay_tile_at(n, T, t0, v) + off;         // elements j < TS - off
+    const double *p1 = tiles + delay_tile_at(n, T, t1, v) + off - TS;    // the others
     const int split = TS - off;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
         old[j] = (j < split ? p0 : p1)[j];
 }
 
-__device__ __forceinline__ void delay_write8(double *tiles, size_t n, int g, int s8, int v,
+__device__ __forceinline__ void delay_write8(double *tiles, size_t n, int T, int g, int s8, int v,
                                              const double (&w)[8])
 {
-    double2 *dst = reinterpret_cast<double2 *>(tiles + ((size_t)g * n + (size_t)v) * kDelayTile + 8 * s8);
+    double2 *dst = reinterpret_cast<double2 *>(tiles + delay_tile_at(n, T, g, v) + 8 * s8);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         dst[j] = make_double2(w[2 * j], w[2 * j + 1]);
@@ -289,16 +309,63 @@ __device__ __forceinline__ void delay_write8(double *tiles, size_t n, int g, int
 
 // a whole tile of 16 samples (kDelayTile == 16): the group before this one (`lo`) and this one
 // (`hi`) as ONE 128-byte piece per voice -- a full cache line, never half of one
-__device__ __forceinline__ void delay_write16(double *tiles, size_t n, int g, int v,
+__device__ __forceinline__ void delay_write16(double *tiles, size_t n, int T, int g, int v,
                                               const double (&lo)[8], const double (&hi)[8])
 {
-    double2 *dst = reinterpret_cast<double2 *>(tiles + ((size_t)g * n + (size_t)v) * 16);
+    double2 *dst = reinterpret_cast<double2 *>(tiles + delay_tile_at(n, T, g, v));
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         dst[j] = make_double2(lo[2 * j], lo[2 * j + 1]);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         dst[4 + j] = make_double2(hi[2 * j], hi[2 * j + 1]);
+}
+
+// The same eight samples from a window the lane carries in registers: `prev` and `cur` are the
+// voice's time groups a and a + 1 (eight samples each), a = this group - length / 8 - 1; the delayed samples are
+// elements 8 - length % 8 .. of the two, i.e. window[1 + k + j] with k = 7 - length % 8.  A lane
+// then reads every tile of its line exactly once, as one aligned 64-byte piece, whatever its
+// delay time; read in two unaligned parts (delay_read8), each tile is fetched in two consecutive
+// groups, and with 65,536 different times the second fetch misses the cache (measured: twice
+// the algorithmic read traffic).  The shift by k is three rounds of selects.
+// (written with constant indices throughout -- index packs, no loops: a loop's variable index
+// lets the optimiser turn "c ? w[i + 4] : w[i]" into one load at a selected ADDRESS, which
+// puts the window into scratch memory)
+template <int BY, int... I>
+__device__ __forceinline__ void delay_shift_round(const double *in, double *out, bool c,
+                                                  std::integer_sequence<int, I...>)
+{
+    ((out[I] = c ? in[I + BY] : in[I]), ...);
+}
+template <int... I>
+__device__ __forceinline__ void delay_window_fill(const double (&prev)[8], const double (&cur)[8],
+                                                  double *w0, std::integer_sequence<int, I...>)
+{
+    ((w0[I] = I < 7 ? prev[(I + 1) & 7] : cur[(I - 7) & 7]), ...);
+}
+__device__ __forceinline__ void delay_window8(const double (&prev)[8], const double (&cur)[8], int k,
+                                              double (&old)[8])
+{
+    double w0[15], w1[11], w2[9];
+    delay_window_fill(prev, cur, w0, std::make_integer_sequence<int, 15>{});
+    delay_shift_round<4>(w0, w1, (k & 4) != 0, std::make_integer_sequence<int, 11>{});
+    delay_shift_round<2>(w1, w2, (k & 2) != 0, std::make_integer_sequence<int, 9>{});
+    delay_shift_round<1>(w2, old, (k & 1) != 0, std::make_integer_sequence<int, 8>{});
+}
+
+// the eight samples of time group `grp` (absolute sample time / 8, reduced modulo T * TS / 8) of
+// voice v: four 16-byte loads of an aligned 64-byte piece -- a tile, or half of a 16-sample one
+__device__ __forceinline__ void delay_load_group8(const double *tiles, size_t n, int T, int grp, int v,
+                                                  double (&d)[8])
+{
+    constexpr int GPT = kDelayTile / 8;
+    const double2 *src = reinterpret_cast<const double2 *>(tiles + delay_tile_at(n, T, grp / GPT, v) +
+                                                           8 * (grp % GPT));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double2 p = src[j];
+        d[2 * j] = p.x, d[2 * j + 1] = p.y;
+    }
 }
 
 // tile index of the first sample of absolute block `clock`: (clock * tiles per block) % T

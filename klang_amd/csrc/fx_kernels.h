@@ -19,6 +19,9 @@
 // the Tremolo's remainder has its own check and exact form.  Per sample the arithmetic is the
 // reference's, operation for operation, and equal to voice_mod_kernel's bit for bit.
 #pragma once
+#ifndef KLMI_DELAY_CARRY
+#define KLMI_DELAY_CARRY 1
+#endif
 #include "bank_kernels.h"
 #include <type_traits>
 
@@ -162,6 +165,16 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
     }
     double held = 0.;   // Subsampler: the sample being repeated (at most one per chain)
     double wstash[G] = {};   // Delay, 16-sample tiles: the first half of the tile being written
+    // Delay: the lane carries the older group of its two-group window (delay_window8)
+    constexpr bool CARRY = DELAY >= 0 && KLMI_DELAY_CARRY;
+    constexpr int GPT = kDelayTile / 8;   // time groups per tile
+    double dprev[G] = {};
+    const int delay_back = delay_len / 8 + 1, delay_shift = 7 - delay_len % 8;
+    if constexpr (CARRY) {
+        int ga = delay_tile_of_block(clock_base, delay_tiles) * GPT - delay_back;
+        ga = ga < 0 ? ga + delay_tiles * GPT : ga;
+        delay_load_group8(bk.fx_ring, n, delay_tiles, ga, v, dprev);
+    }
 
     double gl = 0., gr = 0.;
     if (MIX) {
@@ -292,13 +305,19 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
             for (int i8 = 0; i8 < CH; i8 += G) {
                 const Time8 tt = times[i8 >> 3];
                 // the Delay's eight delayed samples, asked for first
-                double old[G] = {};
+                double old[G] = {}, dcur[G] = {};
                 int ttile = 0, tsub = 0;   // wave-uniform: time tile of this group, group in the tile
                 if constexpr (DELAY >= 0) {
                     ttile = block_tile + (c * CH + i8) / kDelayTile;
                     ttile = ttile >= delay_tiles ? ttile - delay_tiles : ttile;
                     tsub = ((c * CH + i8) % kDelayTile) >> 3;
-                    delay_read8(bk.fx_ring, n, delay_tiles, ttile, tsub, delay_len, v, old);
+                    if constexpr (CARRY) {
+                        int gb = ttile * GPT + tsub - delay_back + 1;
+                        gb = gb < 0 ? gb + delay_tiles * GPT : gb;
+                        delay_load_group8(bk.fx_ring, n, delay_tiles, gb, v, dcur);
+                    } else {
+                        delay_read8(bk.fx_ring, n, delay_tiles, ttile, tsub, delay_len, v, old);
+                    }
                 }
 
                 double osc[G];
@@ -437,6 +456,12 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
                         }
                     } else if (kind == FX_DELAY) {     // effects.py:166-174: wet = new + feedback * delayed
                         double w[G];
+                        if constexpr (CARRY) {
+                            delay_window8(dprev, dcur, delay_shift, old);
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                dprev[j] = dcur[j];
+                        }
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             w[j] = y[j] + delay_fb * old[j];
@@ -447,10 +472,10 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
                                 for (int j = 0; j < G; ++j)
                                     wstash[j] = w[j];
                             } else if (live) {
-                                delay_write16(bk.fx_ring, n, ttile, v, wstash, w);
+                                delay_write16(bk.fx_ring, n, delay_tiles, ttile, v, wstash, w);
                             }
                         } else if (live) {
-                            delay_write8(bk.fx_ring, n, ttile, tsub, v, w);
+                            delay_write8(bk.fx_ring, n, delay_tiles, ttile, tsub, v, w);
                         }
 #pragma unroll
                         for (int j = 0; j < G; ++j)

@@ -768,7 +768,7 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
     b->fx_block_major = any_short;
     const int stride = any_short ? (need + KLMI_BUFFER_SIZE + 15) & ~15 : 0;
     const int tiles = any_short ? 0 : need / kDelayTile + 3;
-    const size_t len = any_short ? (size_t)stride * n : (size_t)tiles * n * kDelayTile;
+    const size_t len = any_short ? (size_t)stride * n : delay_tiles_len(n, tiles);
     DevBuf<double> grown;
     hipError_t e = grown.alloc(len);
     if (e != hipSuccess)
@@ -784,12 +784,22 @@ static int ensure_fx_ring(klmi_bank *b, bool may_alloc = true)
     } else if (b->fx_ring_cap > 0) {
         // the tiles of the last T_old - 1 time groups move to their places modulo the new T
         const unsigned long long now = (unsigned long long)b->block_clock * (kBlock / kDelayTile);
-        const size_t row = n * kDelayTile;
-        for (int k = 1; k < b->fx_ring_tiles && (unsigned long long)k <= now; ++k) {
+        const int old_tiles = b->fx_ring_tiles;
+        for (int k = 1; k < old_tiles && (unsigned long long)k <= now; ++k) {
             const unsigned long long g = now - (unsigned long long)k;
-            HIP_TRY(hipMemcpyAsync(grown.p + (size_t)(g % (unsigned)tiles) * row,
-                                   b->fx_ring.p + (size_t)(g % (unsigned)b->fx_ring_tiles) * row,
-                                   sizeof(double) * row, hipMemcpyDeviceToDevice, st));
+            const int to = (int)(g % (unsigned)tiles), from = (int)(g % (unsigned)old_tiles);
+            if (KLMI_DELAY_WAVE_MAJOR) {
+                // one 64-voice piece of the tile per wavefront region
+                const size_t piece = sizeof(double) * 64 * kDelayTile;
+                HIP_TRY(hipMemcpy2DAsync(grown.p + delay_tile_at(n, tiles, to, 0), piece * tiles,
+                                         b->fx_ring.p + delay_tile_at(n, old_tiles, from, 0),
+                                         piece * old_tiles, piece, (n + 63) / 64,
+                                         hipMemcpyDeviceToDevice, st));
+            } else {
+                HIP_TRY(hipMemcpyAsync(grown.p + delay_tile_at(n, tiles, to, 0),
+                                       b->fx_ring.p + delay_tile_at(n, old_tiles, from, 0),
+                                       sizeof(double) * n * kDelayTile, hipMemcpyDeviceToDevice, st));
+            }
         }
     } else {
         HIP_TRY(hipMemsetAsync(b->f64(SL_FX_STATE + 2 * b->fx_delay_stage), 0, sizeof(double) * n, st));
@@ -824,7 +834,23 @@ static int reset_changed_delay_lines(klmi_bank *b, int first, int count, const d
                 if (b->fx_block_major)
                     HIP_TRY(hipMemsetAsync(b->fx_ring.p + (size_t)(first + run) * b->fx_ring_stride, 0,
                                            sizeof(double) * (size_t)(i - run) * b->fx_ring_stride, st));
-                else    // the voices' columns of every tile
+                else if (KLMI_DELAY_WAVE_MAJOR) {   // the voices' columns of every tile, wavefront by wavefront
+                    for (int v0 = first + run; v0 < first + i;) {
+                        if (v0 % 64 == 0 && first + i - v0 >= 64) {   // whole wavefront regions: contiguous
+                            const int v1 = v0 + (first + i - v0) / 64 * 64;
+                            HIP_TRY(hipMemsetAsync(b->fx_ring.p + delay_tile_at(n, b->fx_ring_tiles, 0, v0), 0,
+                                                   sizeof(double) * (size_t)(v1 - v0) * b->fx_ring_tiles * kDelayTile, st));
+                            v0 = v1;
+                            continue;
+                        }
+                        const int v1 = std::min(first + i, (v0 / 64 + 1) * 64);
+                        HIP_TRY(hipMemset2DAsync(b->fx_ring.p + delay_tile_at(n, b->fx_ring_tiles, 0, v0),
+                                                 sizeof(double) * 64 * kDelayTile, 0,
+                                                 sizeof(double) * (size_t)(v1 - v0) * kDelayTile,
+                                                 (size_t)b->fx_ring_tiles, st));
+                        v0 = v1;
+                    }
+                } else
                     HIP_TRY(hipMemset2DAsync(b->fx_ring.p + (size_t)(first + run) * kDelayTile,
                                              sizeof(double) * n * kDelayTile, 0,
                                              sizeof(double) * (size_t)(i - run) * kDelayTile,

@@ -730,10 +730,10 @@ __global__ __launch_bounds__(kGroup) void voice_mod_kernel(BankView bk, int has_
                                         for (int j = 0; j < G; ++j)
                                             wstash[j] = w[j];
                                     } else if (live) {
-                                        delay_write16(bk.fx_ring, n, ttile, v, wstash, w);
+                                        delay_write16(bk.fx_ring, n, bk.fx_ring_tiles, ttile, v, wstash, w);
                                     }
                                 } else if (live) {
-                                    delay_write8(bk.fx_ring, n, ttile, tsub, v, w);
+                                    delay_write8(bk.fx_ring, n, bk.fx_ring_tiles, ttile, tsub, v, w);
                                 }
 #pragma unroll
                                 for (int j = 0; j < G; ++j)
