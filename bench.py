@@ -86,27 +86,30 @@ def extra_records(ctx, native, patches, torch, log):
             allev.append(e)
         bank.events(np.concatenate(allev))
 
-    # -- config 3 materialised: A3m = 4.594 B per voice-sample
-    n, nb = 65536, 256
-    patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=10, off_span=20)
-    bank = native.Bank(ctx, n, has_env=True, has_filter=True)
-    bank.load_patch(patch)
-    buf = torch.empty((n, nb * B), dtype=torch.float32, device='cuda')
-    wall, kern, launches = timed(bank, nb, lambda: bank.render_voices_device(nb, buf.data_ptr()))
-    units, ms = n * nb * B, stats(kern)['median']
-    gbs = units * 4.594 / (ms * 1e-3) / 1e9
-    out['materialised'] = {
-        'workload': 'config 3 materialised: 65,536 voices x %d blocks, one float32 stream per '
-                    'voice written to HBM (klmi_bank_render_voices_device)' % nb,
-        'value': units / (ms * 1e-3), 'unit': 'voice-samples/s', 'kernel_ms': stats(kern),
-        'wall_ms': stats([w * 1e3 for w in wall]),
-        'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': gbs / HBM_PEAK_GBS, 'frac_of_probe_fill': gbs / rates['fill'],
-                     'algorithmic_bytes_per_voice_sample': 4.594,
-                     'kernel': 'voice_kernel<env,biquad,voices_f32>'}}
-    del buf
-    bank.close()
-    log('materialised: %.3g voice-samples/s, %.0f GB/s' % (units / (ms * 1e-3), gbs))
+    # -- config 3 materialised: A3m = 4.594 B per voice-sample.  At 65,536 voices (one
+    # wave per SIMD) the mode is bound by the same float64 arithmetic as the mixed-down headline;
+    # the 131,072-voice bank (two waves per SIMD, the per-GPU shard of configs[4]) shows what the
+    # store path reaches when the arithmetic leaves it room
+    for n, nb in ((65536, 256), (VOICES_SHARD, 128)):
+        patch = patches.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=10, off_span=20)
+        bank = native.Bank(ctx, n, has_env=True, has_filter=True)
+        bank.load_patch(patch)
+        buf = torch.empty((n, nb * B), dtype=torch.float32, device='cuda')
+        wall, kern, launches = timed(bank, nb, lambda: bank.render_voices_device(nb, buf.data_ptr()))
+        units, ms = n * nb * B, stats(kern)['median']
+        gbs = units * 4.594 / (ms * 1e-3) / 1e9
+        out['materialised' if n == 65536 else 'materialised_%d' % n] = {
+            'workload': 'config 3 materialised: %d voices x %d blocks, one float32 stream per '
+                        'voice written to HBM (klmi_bank_render_voices_device)' % (n, nb),
+            'value': units / (ms * 1e-3), 'unit': 'voice-samples/s', 'kernel_ms': stats(kern),
+            'wall_ms': stats([w * 1e3 for w in wall]),
+            'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': gbs / HBM_PEAK_GBS, 'frac_of_probe_fill': gbs / rates['fill'],
+                         'algorithmic_bytes_per_voice_sample': 4.594,
+                         'kernel': 'voice_kernel<env,biquad,voices_f32>'}}
+        del buf
+        bank.close()
+        log('materialised, %d voices: %.3g voice-samples/s, %.0f GB/s' % (n, units / (ms * 1e-3), gbs))
 
     # -- BASELINE configs[3]: reverb channels, delay lines in HBM.  A4 = 10 combs x
     # (read + write) x ring width; the dry voice is made inside the reverb wave, so no dry bus

@@ -1,0 +1,152 @@
+"""Seeded random chains against the oracle: every draw combines features that the other test
+files cover one at a time -- bank size, envelope / filter / stereo, wave functions per voice,
+an audio-rate modulation input, the block-rate cutoff Lfo, a stage program of up to three
+effects (delay lines on either side of one buffer), the kernel family (the pipelined kernel for
+small banks or one lane per voice) and the way the span is cut into launches.  Only IEEE basic
+operations are drawn (no sine, no tanh), so float64 voice streams and all state must equal the
+oracle's bit for bit; the float32 mix within 1e-6.  Everything goes through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from klang_amd import patches as P
+from tests.helpers import B, library_table, oracle_bank_from_patch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (1, 37, 64, 65, 200, 333, 513)
+
+
+@pytest.fixture(scope='module')
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def draw(hip, rng):
+    n = int(rng.choice(SIZES))
+    nb = int(rng.integers(3, 11))
+    cfg = dict(n=n, nb=nb, has_env=bool(rng.random() < .85), has_filter=bool(rng.random() < .6),
+               stereo=bool(rng.random() < .3))
+    target = int(rng.choice([hip.MOD_NONE, hip.MOD_NONE, hip.MOD_NONE, hip.MOD_FM, hip.MOD_FREQUENCY,
+                             hip.MOD_DUTY]))
+    cfg['target'] = target
+    cfg['cutoff_lfo'] = bool(cfg['has_filter'] and rng.random() < .25)
+    if target == hip.MOD_DUTY:
+        wave = np.full(n, P.WAVE_PWM)
+    elif rng.random() < .5:          # wavefronts that agree on their wave function
+        wave = np.repeat(rng.integers(1, 5, -(-n // 64)), 64)[:n]
+    else:
+        wave = rng.integers(1, 5, n)
+    cfg['wave'] = wave.astype(np.int32)
+    cfg['duty'] = .1 + .8 * rng.random(n)
+    # a stage program: at most one stage of each kind that keeps state
+    kinds = []
+    pool = ['T', 'D', 'G', 'X', 'O', 'B', 'S']
+    for _ in range(int(rng.choice([0, 0, 1, 2, 3]))):
+        k = str(rng.choice(pool))
+        kinds.append(k)
+        if k in 'TDS':
+            pool.remove(k)
+    cfg['program'] = ''.join(kinds)
+    cfg['short_delay'] = bool(rng.random() < .3)
+    cfg['pipe_off'] = bool(rng.random() < .5)
+    cuts = sorted(set(int(c) for c in rng.integers(1, nb, int(rng.integers(0, 3)))))
+    cfg['launches'] = [b - a for a, b in zip([0] + cuts, cuts + [nb])]
+    return cfg
+
+
+def stage_of(hip, rng, k, n, short_delay):
+    if k == 'T':
+        rate = 1. + 9. * rng.random(n)
+        rate[rng.random(n) < .05] *= -1.
+        return (hip.FX_TREMOLO, rate, rng.random(n), rng.random(n), .1 + .8 * rng.random(n))
+    if k == 'D':
+        time = (3 + rng.integers(0, 250, n)) / 44100. + 1e-7 if short_delay else .006 + .04 * rng.random(n)
+        return (hip.FX_DELAY, time, .9 * rng.random(n), rng.random(n))
+    if k == 'G':
+        return (hip.FX_GAIN, 1.5 * rng.random(n))
+    if k == 'X':
+        return (hip.FX_TRANSFORM, .5 + rng.random(n), rng.random(n) - .5)
+    if k == 'O':
+        return (hip.FX_OCTAVE,)
+    if k == 'B':
+        return (hip.FX_BITCRUSH, rng.integers(0, 16, n))
+    return (hip.FX_SUBSAMPLE, 2 ** rng.integers(1, 8, n))
+
+
+# KLANG_FUZZ_SEEDS widens a hunt; the default keeps the file at a few seconds
+@pytest.mark.parametrize('seed', range(int(os.environ.get('KLANG_FUZZ_SEEDS', '60'))))
+def test_random_chain_vs_oracle_bit_exact(hip, ctx, oracle, monkeypatch, seed):
+    rng = np.random.default_rng(9000 + seed)
+    cfg = draw(hip, rng)
+    n, nb = cfg['n'], cfg['nb']
+    if cfg['pipe_off']:
+        monkeypatch.setenv('KLMI_PIPE_VOICES_LOG2', '-1')
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, seed=seed, off_base=2, off_span=max(1, nb // 2))
+    patch['has_env'], patch['has_filter'], patch['stereo'] = cfg['has_env'], cfg['has_filter'], cfg['stereo']
+    patch['wave'] = cfg['wave']
+    patch['pan'] = 2. * rng.random(n) - 1.
+    patch['gain'] = .2 + rng.random(n)
+    stages = ([(hip.FX_FILTER,)] if cfg['has_filter'] and cfg['program'] else []) + \
+        [stage_of(hip, rng, k, n, cfg['short_delay']) for k in cfg['program']]
+    table, grid = library_table(hip)
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.duty[:] = cfg['duty']
+    hb = hip.Bank(ctx, n, has_env=cfg['has_env'], has_filter=cfg['has_filter'], stereo=cfg['stereo'],
+                  cutoff_lfo=cfg['cutoff_lfo'], mod_target=cfg['target'], effects=[s[0] for s in stages])
+    hb.load_patch(patch)
+    hb.set(hip.F_DUTY, cfg['duty'])
+    if stages:
+        ob.set_effects(stages)
+        for s, st in enumerate(stages):
+            for k, p in enumerate(st[1:]):
+                hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+    wv = rng.integers(1, 4, n)
+    if cfg['cutoff_lfo']:
+        lf, ls, lo = .5 + 20. * rng.random(n), 200. + 1000. * rng.random(n), 1500. + 1000. * rng.random(n)
+        lp = 6. * rng.random(n)
+        ob.cutoff_lfo, ob.grid = True, grid
+        ob.lfo_frequency, ob.lfo_scale, ob.lfo_offset, ob.lfo_phase = lf, ls, lo, lp.copy()
+        ob.lfo_wave = wv.astype(np.int32)
+        hb.set(hip.F_LFO_FREQUENCY, lf), hb.set(hip.F_LFO_SCALE, ls), hb.set(hip.F_LFO_OFFSET, lo)
+        hb.set(hip.F_LFO_WAVE, wv), hb.set_state(hip.F_LFO_PHASE, lp)
+    target = cfg['target']
+    if target != hip.MOD_NONE:
+        mf = 1. + 200. * rng.random(n)
+        if target == hip.MOD_FM:
+            ms, mo = 3. * rng.random(n), np.zeros(n)
+        elif target == hip.MOD_FREQUENCY:
+            ms, mo = 30. * rng.random(n), patch.frequency.copy()
+        else:
+            ms, mo = .4 * rng.random(n), np.full(n, .5)
+        mp = 6. * rng.random(n)
+        mw = rng.integers(1, 4, n)
+        if target == hip.MOD_FM and rng.random() < .5:     # paired as FmOscillator builds them
+            mw = np.minimum(cfg['wave'], 3)
+        ob.mod_target = target
+        ob.mod_frequency, ob.mod_scale, ob.mod_offset, ob.mod_phase = mf, ms, mo, mp.copy()
+        ob.mod_wave = mw.astype(np.int32)
+        hb.set(hip.F_MOD_FREQUENCY, mf), hb.set(hip.F_MOD_SCALE, ms), hb.set(hip.F_MOD_OFFSET, mo)
+        hb.set(hip.F_MOD_WAVE, mw), hb.set_state(hip.F_MOD_PHASE, mp)
+
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+    note = 'draw %r' % {k: v for k, v in cfg.items() if k not in ('wave', 'duty')}
+    np.testing.assert_array_equal(hb.render_voices(nb, f64=True), want_voices, err_msg=note)
+    mix = np.concatenate([hb.render(k) for k in cfg['launches']])
+    assert mix.shape == want_mix.shape == (nb, 2 if cfg['stereo'] else 1, B), note
+    assert np.abs(mix - want_mix).max() <= 1e-6 * max(1., np.abs(want_mix).max()), note
+    np.testing.assert_array_equal(hb.get_state(hip.F_PHASE), ob.phase, err_msg=note)
+    if cfg['has_filter']:
+        np.testing.assert_array_equal(hb.get_state(hip.F_Z0), ob.z0, err_msg=note)
+        np.testing.assert_array_equal(hb.get_state(hip.F_Z1), ob.z1, err_msg=note)
+    if cfg['cutoff_lfo']:
+        np.testing.assert_array_equal(hb.get_state(hip.F_LFO_PHASE), ob.lfo_phase, err_msg=note)
+    if target != hip.MOD_NONE:
+        np.testing.assert_array_equal(hb.get_state(hip.F_MOD_PHASE), ob.mod_phase, err_msg=note)
+    for s, st in enumerate(stages):
+        if st[0] in (hip.FX_TREMOLO, hip.FX_DELAY):
+            np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(s, 0)), ob.fx_state[s, 0], err_msg=note)
+    hb.close()
