@@ -150,3 +150,66 @@ def test_random_chain_vs_oracle_bit_exact(hip, ctx, oracle, monkeypatch, seed):
         if st[0] in (hip.FX_TREMOLO, hip.FX_DELAY):
             np.testing.assert_array_equal(hb.get_state(hip.F_FX_STATE(s, 0)), ob.fx_state[s, 0], err_msg=note)
     hb.close()
+
+
+def oracle_rings(reverb):
+    c = reverb.c
+    rings = [np.ctypeslib.as_array(c.filters[k].data, shape=(c.filters[k].length,)).copy()
+             for k in range(c.n_echos)]
+    return rings, [int(c.filters[k].position) for k in range(c.n_echos)]
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('KLANG_FUZZ_SEEDS', '30'))))
+def test_random_reverb_bank_vs_oracle(hip, ctx, oracle, monkeypatch, seed):
+    """Voice -> [Filter] -> Reverb -> Mixer / StereoMixer banks with drawn comb counts, pre-delays on
+    either side of the 256-sample pass, the fused or the two-kernel path, voices per wavefront
+    and launch cuts; float64 rings under non-sine wave functions: the delay lines must equal the
+    oracle's bit for bit, the mix within 1e-6."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 5, 64, 100, 257, 300]))
+    nb = int(rng.integers(4, 15))
+    kw = dict(decay=float(.5 + 2.5 * rng.random()),
+              pre_delay=float(rng.choice([.0001, .002, .006, .01, .03, .05])),
+              dry_wet=float(rng.random()), n_echos=int(rng.choice([10, 10, 10, 7, 16])), rings='f64')
+    stereo, has_env, has_filter = bool(rng.random() < .3), bool(rng.random() < .8), bool(rng.random() < .3)
+    if rng.random() < .5:
+        monkeypatch.setenv('KLMI_REVERB_FUSED', '0')
+    vpw = str(rng.choice(['', '1', '2', '4']))
+    if vpw:
+        monkeypatch.setenv('KLMI_REVERB_VPW', vpw)
+    patch = P.reverb_patch(n_channels=n, n_blocks=nb, seed=seed, period=int(rng.integers(3, 9)),
+                           note_blocks=int(rng.integers(1, 4)))
+    patch['reverb'] = kw
+    patch['stereo'], patch['has_env'], patch['has_filter'] = stereo, has_env, has_filter
+    patch['wave'] = rng.integers(1, 4, n).astype(np.int32)
+    patch['gain'] = .5 + rng.random(n)
+    patch['pan'] = 2. * rng.random(n) - 1.
+    table, grid = library_table(hip)
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    _, dry = ob.render(nb, patch.events, want_voices=True)
+    reverbs = [oracle.OracleReverb(kw['decay'], kw['pre_delay'], kw['dry_wet'], kw['n_echos'])
+               for _ in range(n)]
+    wet = np.stack([r.run(dry[v]) for v, r in enumerate(reverbs)])
+    if stereo:
+        pan = np.array([oracle.panning_amplitudes(p) for p in patch.pan])
+        want = np.einsum('vc,vs->cs', patch.gain[:, None] * pan, wet) / n
+        want = want.reshape(2, nb, B).transpose(1, 0, 2)
+    else:
+        want = ((patch.gain[:, None] * wet).sum(axis=0) / n).reshape(nb, 1, B)
+    bank = hip.Bank(ctx, n, has_env=has_env, has_filter=has_filter, stereo=stereo, has_reverb=True,
+                    reverb=kw)
+    bank.load_patch(patch)
+    cuts = sorted(set(int(c) for c in rng.integers(1, nb, int(rng.integers(0, 3)))))
+    launches = [b - a for a, b in zip([0] + cuts, cuts + [nb])]
+    mix = np.concatenate([bank.render(k) for k in launches])
+    note = 'draw n=%d nb=%d %r stereo=%s env=%s filter=%s launches=%r vpw=%r' % (
+        n, nb, kw, stereo, has_env, has_filter, launches, vpw)
+    assert mix.shape == want.shape, note
+    assert np.abs(mix - want).max() <= 1e-6 * max(1., np.abs(want).max()), note
+    for v in sorted(set([0, n // 2, n - 1])):
+        rings, pos = bank.reverb_state(v)
+        o_rings, o_pos = oracle_rings(reverbs[v])
+        assert list(pos) == o_pos, note
+        for got, ref in zip(rings, o_rings):
+            np.testing.assert_array_equal(got, ref, err_msg=note)
+    bank.close()
