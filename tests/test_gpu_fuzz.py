@@ -213,3 +213,68 @@ def test_random_reverb_bank_vs_oracle(hip, ctx, oracle, monkeypatch, seed):
         for got, ref in zip(rings, o_rings):
             np.testing.assert_array_equal(got, ref, err_msg=note)
     bank.close()
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('KLANG_FUZZ_SEEDS', '30'))))
+def test_random_synthesizer_bank_vs_oracle(hip, ctx, oracle, seed):
+    """PolyphonicSynthesizer banks with drawn voice counts, instrument counts (instrument
+    boundaries inside wavefronts), per-voice envelopes and wave functions, optional FM, random
+    chords with note-offs and launch cuts: voice streams and all routing / envelope / phase state
+    equal the oracle's bit for bit."""
+    rng = np.random.default_rng(5000 + seed)
+    poly = int(rng.choice([1, 2, 3, 5, 8, 24]))
+    n_inst = int(rng.choice([1, 7, 30, 100]))
+    nb = int(rng.integers(6, 21))
+    n = poly * n_inst
+    attack, decay = .001 + .02 * rng.random(n), .005 + .05 * rng.random(n)
+    sustain, release = .2 + .7 * rng.random(n), .005 + .05 * rng.random(n)
+    wave = rng.integers(1, 4, n).astype(np.int32)
+    ob = oracle.OracleBank(n, has_env=True, has_filter=False)
+    ob.wave[:] = wave
+    ob.set_envelopes(attack, decay, sustain, release)
+    fm = bool(rng.random() < .25)
+    kw = {}
+    if fm:
+        kw['mod_target'] = hip.MOD_FM
+        ob.mod_target = oracle.MOD_FM
+        ob.mod_frequency[:] = 50. + 100. * rng.random(n)
+        ob.mod_scale[:] = 2. * rng.random(n)
+        ob.mod_wave[:] = rng.integers(1, 4, n)
+    bank = hip.Bank(ctx, n, has_env=True, poly_voices=poly, **kw)
+    bank.set(hip.F_WAVE, wave)
+    for field, value in ((hip.F_ATTACK, attack), (hip.F_DECAY, decay), (hip.F_SUSTAIN, sustain),
+                         (hip.F_RELEASE, release)):
+        bank.set(field, value)
+    if fm:
+        bank.set(hip.F_MOD_FREQUENCY, ob.mod_frequency)
+        bank.set(hip.F_MOD_SCALE, ob.mod_scale)
+        bank.set(hip.F_MOD_WAVE, ob.mod_wave)
+    rows = []
+    for inst in range(n_inst):
+        for _ in range(int(rng.integers(0, 3 * poly + 4))):
+            blk = int(rng.integers(0, nb - 1))
+            pitch = int(rng.integers(36, 96))
+            f = 440. * 2 ** ((pitch - 69) / 12)
+            rows.append((inst, blk, pitch, 0, .2 + .8 * rng.random(), f))
+            if rng.random() < .8:
+                rows.append((inst, min(nb - 1, blk + int(rng.integers(0, 6))), pitch, 0, 0., f))
+    notes = np.array(rows, dtype=oracle.NOTE_DTYPE) if rows else np.zeros(0, dtype=oracle.NOTE_DTYPE)
+    bank.notes(notes)
+    want_out, want_voices = ob.render_synth(poly, nb, notes, want_voices=True)
+    note = 'draw poly=%d instruments=%d nb=%d fm=%s notes=%d' % (poly, n_inst, nb, fm, len(notes))
+    np.testing.assert_array_equal(bank.render_voices(nb, f64=True), want_voices, err_msg=note)
+    bank.set_mix_divisor(poly * n_inst)
+    cuts = sorted(set(int(c) for c in rng.integers(1, nb, int(rng.integers(0, 3)))))
+    launches = [b - a for a, b in zip([0] + cuts, cuts + [nb])]
+    mix = np.concatenate([bank.render(k) for k in launches])[:, 0, :].ravel()
+    assert np.abs(mix - want_out.sum(axis=0) / n_inst).max() <= 1e-6, note
+    np.testing.assert_array_equal(bank.get_state(hip.F_PHASE), ob.phase, err_msg=note)
+    np.testing.assert_array_equal(bank.get_state(hip.F_CURRENT_PITCH), ob.current_pitch, err_msg=note)
+    np.testing.assert_array_equal(bank.get_state(hip.F_ROUND_ROBIN), np.repeat(ob.round_robin, poly),
+                                  err_msg=note)
+    stage, value, _ = ob.env_state()
+    np.testing.assert_array_equal(bank.get_state(hip.F_ENV_STAGE), stage, err_msg=note)
+    np.testing.assert_array_equal(bank.get_state(hip.F_ENV_VALUE), value, err_msg=note)
+    if fm:
+        np.testing.assert_array_equal(bank.get_state(hip.F_MOD_PHASE), ob.mod_phase, err_msg=note)
+    bank.close()
