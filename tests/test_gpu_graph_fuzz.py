@@ -1,0 +1,139 @@
+"""Seeded random patches through run_klang: the same patch, built twice from its seed, is
+rendered by the device path (backend='hip': fusion.compile_order turns the chains into banks)
+and by the host blocks (backend='host', the NumPy evaluation that mirrors the reference), and
+the two renderings must agree within the 1e-5 bound.  A draw decides the sink (Mixer /
+StereoMixer, gains, pannings), how many chains it sums, whether they share one structure (one
+bank) or differ (a bank each, summed as external voices), and per chain the source (Voice with
+ADSR / AR / looping AR, bare Oscillator, PwmOscillator, FmOscillator, an audio-rate Lfo on the
+frequency), the Filter and its cutoff Lfo, up to three effect stages and a closing Reverb."""
+import os
+
+import numpy as np
+import pytest
+
+from klang_amd.audio import (ADSR, AR, Bitcrusher, Dac, Delay, Filter, FmOscillator, Gain, Lfo, Mixer,
+                             OctaveDistortion, Oscillator, PwmOscillator, Reverb, RingModulator,
+                             StereoMixer, Subsampler, TanhDistortion, Transformer, Tremolo, Voice,
+                             sawtooth, sine, square, triangle)
+from klang_amd.klang import run_klang
+from klang_amd.messages import Note
+
+pytestmark = pytest.mark.gpu
+B = 256
+WAVES = (sine, square, sawtooth, triangle)
+STAGES = ('tremolo', 'delay', 'short_delay', 'gain', 'transformer', 'octave', 'tanh', 'bitcrusher',
+          'subsampler', 'ringmod')
+
+
+def draw_structure(rng):
+    """What a chain is made of (kinds only; the numbers are drawn per chain)."""
+    st = dict(source=str(rng.choice(['voice', 'voice', 'voice', 'osc', 'pwm', 'fm', 'vibrato'])),
+              in_voice=bool(rng.random() < .7),
+              envelope=str(rng.choice(['adsr', 'ar', 'ar_loop'])),
+              wave=int(rng.integers(0, 4)),
+              filter=bool(rng.random() < .5), cutoff_lfo=bool(rng.random() < .3),
+              reverb=bool(rng.random() < .2))
+    kinds, pool = [], list(STAGES)
+    for _ in range(int(rng.choice([0, 0, 1, 2, 3]))):
+        k = str(rng.choice(pool))
+        kinds.append(k)
+        if k in ('tremolo', 'subsampler', 'ringmod'):
+            pool.remove(k)
+        if k in ('delay', 'short_delay'):
+            pool.remove('delay'), pool.remove('short_delay')
+    st['stages'] = kinds
+    st['filter_at'] = int(rng.integers(0, len(kinds) + 1))
+    return st
+
+
+def make_stage(kind, rng):
+    if kind == 'tremolo':
+        return Tremolo(rate=1. + 8. * rng.random(), depth=rng.random(), smoothness=.1 + .8 * rng.random())
+    if kind == 'delay':
+        return Delay(time=.006 + .03 * rng.random(), feedback=.8 * rng.random(), drywet=rng.random())
+    if kind == 'short_delay':
+        return Delay(time=(3 + int(rng.integers(0, 250))) / 44100. + 1e-7, feedback=.8 * rng.random(),
+                     drywet=rng.random())
+    if kind == 'gain':
+        return Gain(1.5 * rng.random())
+    if kind == 'transformer':
+        return Transformer(.5 + rng.random(), rng.random() - .5)
+    if kind == 'octave':
+        return OctaveDistortion()
+    if kind == 'tanh':
+        return TanhDistortion(.5 + 3. * rng.random())
+    if kind == 'bitcrusher':
+        return Bitcrusher(int(rng.integers(2, 14)))
+    if kind == 'subsampler':
+        return Subsampler(int(2 ** rng.integers(1, 6)))
+    return RingModulator(frequency=100. + 400. * rng.random(), rate=.5 + 4. * rng.random(),
+                         amount=30. * rng.random(), wave_func=WAVES[int(rng.integers(0, 4))],
+                         dryWet=rng.random())
+
+
+def make_chain(st, rng):
+    """-> the block whose output is the chain's."""
+    f = 55. * 2 ** (3. * rng.random())
+    wave = WAVES[st['wave']]
+    if st['source'] == 'pwm':
+        osc = PwmOscillator(frequency=f, dutyCycle=.1 + .8 * rng.random())
+    elif st['source'] == 'fm':
+        osc = FmOscillator(frequency=f, intensity=3. * rng.random(), modFrequency=5. + 200. * rng.random(),
+                           wave_func=wave)
+    else:
+        osc = Oscillator(frequency=f, wave_func=wave, startPhase=6. * rng.random())
+    if st['source'] == 'vibrato':
+        depth = 20. * rng.random()
+        lfo = Lfo(frequency=1. + 10. * rng.random(), wave_func=WAVES[int(rng.integers(0, 4))], shape=B,
+                  outputRange=(f - depth, f + depth))
+        lfo | osc.frequency
+    head = osc
+    if st['source'] == 'voice' or (st['in_voice'] and st['source'] in ('pwm', 'fm')):
+        if st['envelope'] == 'adsr':
+            env = ADSR(.002 + .02 * rng.random(), .005 + .05 * rng.random(), .2 + .7 * rng.random(),
+                       .01 + .05 * rng.random())
+        else:
+            env = AR(.002 + .03 * rng.random(), .01 + .05 * rng.random(), loop=st['envelope'] == 'ar_loop')
+        head = Voice(osc, env)
+        head.input.push(Note(0, .2 + .8 * rng.random(), frequency=f))
+    stages = [make_stage(k, rng) for k in st['stages']]
+    if st['filter']:
+        fil = Filter(frequency=200. + 3000. * rng.random())
+        if st['cutoff_lfo']:
+            Lfo(frequency=.5 + 6. * rng.random(), wave_func=WAVES[int(rng.integers(1, 4))],
+                outputRange=(150., 4000.)) | fil.frequency
+        stages.insert(st['filter_at'], fil)
+    if st['reverb']:
+        stages.append(Reverb(decay=.5 + 2. * rng.random(), preDelay=float(rng.choice([.002, .01, .03])),
+                             dryWet=rng.random()))
+    for stage in stages:
+        head = head | stage
+    return head
+
+
+def build(seed):
+    rng = np.random.default_rng(31000 + seed)
+    stereo = bool(rng.random() < .3)
+    mixer = StereoMixer() if stereo else Mixer()
+    n = int(rng.integers(1, 9))
+    uniform = bool(rng.random() < .6)
+    shape_seed = int(rng.integers(1 << 30))
+    for k in range(n):
+        st = draw_structure(np.random.default_rng(shape_seed + (0 if uniform else k)))
+        mixer += make_chain(st, rng)
+        if stereo:
+            mixer.pannings[-1] = 2. * rng.random() - 1.
+    mixer.gains = [float(g) for g in .2 + rng.random(n)]
+    tail = mixer
+    if not stereo and rng.random() < .25:
+        tail = mixer | make_stage(str(rng.choice(['delay', 'gain', 'tremolo', 'tanh'])), rng)
+    return tail | Dac(nChannels=2 if stereo else 1)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('KLANG_FUZZ_SEEDS', '40'))))
+def test_random_patch_device_equals_host(hip, seed):
+    dur = (10 + seed % 9) * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(build(seed), offline=True, duration=dur, fadeout=0.))
+    want = np.concatenate(run_klang(build(seed), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert got.shape == want.shape and np.abs(want).max() > 1e-3
+    assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
