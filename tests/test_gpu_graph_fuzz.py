@@ -15,7 +15,9 @@ from klang_amd.audio import (ADSR, AR, Bitcrusher, Dac, Delay, Filter, FmOscilla
                              OctaveDistortion, Oscillator, PwmOscillator, Reverb, RingModulator,
                              StereoMixer, Subsampler, TanhDistortion, Transformer, Tremolo, Voice,
                              sawtooth, sine, square, triangle)
+from klang_amd import fusion
 from klang_amd.klang import run_klang
+from klang_amd.schedule import determine_execution_order
 from klang_amd.messages import Note
 
 pytestmark = pytest.mark.gpu
@@ -71,8 +73,8 @@ def make_stage(kind, rng):
                          dryWet=rng.random())
 
 
-def make_chain(st, rng):
-    """-> the block whose output is the chain's."""
+def make_chain(st, rng, voices=None):
+    """-> the block whose output is the chain's (its Voice, if any, is appended to `voices`)."""
     f = 55. * 2 ** (3. * rng.random())
     wave = WAVES[st['wave']]
     if st['source'] == 'pwm':
@@ -96,6 +98,8 @@ def make_chain(st, rng):
             env = AR(.002 + .03 * rng.random(), .01 + .05 * rng.random(), loop=st['envelope'] == 'ar_loop')
         head = Voice(osc, env)
         head.input.push(Note(0, .2 + .8 * rng.random(), frequency=f))
+        if voices is not None:
+            voices.append(head)
     stages = [make_stage(k, rng) for k in st['stages']]
     if st['filter']:
         fil = Filter(frequency=200. + 3000. * rng.random())
@@ -135,5 +139,57 @@ def test_random_patch_device_equals_host(hip, seed):
     dur = (10 + seed % 9) * B / 44100. + 1e-9
     got = np.concatenate(run_klang(build(seed), offline=True, duration=dur, fadeout=0.))
     want = np.concatenate(run_klang(build(seed), offline=True, duration=dur, fadeout=0., backend='host'))
+    assert got.shape == want.shape and np.abs(want).max() > 1e-3
+    assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
+
+
+def build_live(seed):
+    """A mixer of Voice chains and the notes that arrive while it plays:
+    -> (mixer, voices, {buffer: [(voice index, Note), ...]})."""
+    rng = np.random.default_rng(47000 + seed)
+    stereo = bool(rng.random() < .3)
+    mixer = StereoMixer() if stereo else Mixer()
+    n = int(rng.integers(1, 13))
+    st = draw_structure(np.random.default_rng(int(rng.integers(1 << 30))))
+    st['source'] = str(rng.choice(['voice', 'pwm', 'fm']))
+    st['in_voice'] = True
+    voices = []
+    for k in range(n):
+        mixer += make_chain(st, rng, voices)
+        if stereo:
+            mixer.pannings[-1] = 2. * rng.random() - 1.
+    n_buffers = int(rng.integers(8, 20))
+    script = {}
+    for _ in range(int(rng.integers(0, 4 * n + 1))):
+        v = int(rng.integers(0, n))
+        pitch = int(rng.integers(36, 90))
+        velocity = 0. if rng.random() < .4 else float(.2 + .8 * rng.random())
+        script.setdefault(int(rng.integers(1, n_buffers)), []).append((v, Note(pitch, velocity)))
+    return mixer, voices, script, n_buffers
+
+
+def play(order, mixer, voices, script, n_buffers):
+    out = []
+    for b in range(n_buffers):
+        for v, note in script.get(b, ()):
+            voices[v].input.push(note)
+        for blk in order:
+            blk.update()
+        out.append(np.array(mixer.output.value, dtype=float))
+    return np.array(out)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('KLANG_FUZZ_SEEDS', '40'))))
+def test_random_live_notes_device_equals_host(hip, seed):
+    """Notes pushed between buffers (Voice.input, voices.py:55-64) into a compiled order (one
+    buffer at a time) and into the host blocks: the same buses, buffer by buffer."""
+    mixer, voices, script, n_buffers = build_live(seed)
+    want = play(determine_execution_order([mixer]), mixer, voices, script, n_buffers)
+    mixer, voices, script, n_buffers = build_live(seed)
+    order, banks = fusion.compile_order(determine_execution_order([mixer]))
+    assert any(type(b).__name__ == 'GpuVoiceBank' for b in order)
+    got = play(order, mixer, voices, script, n_buffers)
+    for bank in banks:
+        bank.close()
     assert got.shape == want.shape and np.abs(want).max() > 1e-3
     assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
