@@ -193,3 +193,63 @@ def test_random_live_notes_device_equals_host(hip, seed):
         bank.close()
     assert got.shape == want.shape and np.abs(want).max() > 1e-3
     assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
+
+
+def build_synths(seed):
+    """NoteScripts into Poly- / MonophonicSynthesizers (and a Kick now and then), alone or under
+    a Mixer / StereoMixer, sometimes with an effect behind: the drum-machine family of patches."""
+    from klang_amd.audio import Kick, MonophonicSynthesizer, PolyphonicSynthesizer
+    from klang_amd.notes import NoteScript
+    rng = np.random.default_rng(59000 + seed)
+    n_buffers = int(rng.integers(12, 40))
+    n_src = int(rng.integers(1, 5))
+    stereo = bool(n_src > 1 and rng.random() < .3)
+    sources = []
+    for _ in range(n_src):
+        kind = str(rng.choice(['poly', 'poly', 'mono', 'kick']))
+        script = {}
+        for _ in range(int(rng.integers(1, 25))):
+            pitch = int(rng.integers(36, 90))
+            on = int(rng.integers(0, n_buffers - 1))
+            script.setdefault(on, []).append(Note(pitch, float(.2 + .8 * rng.random())))
+            if rng.random() < .8:
+                script.setdefault(min(n_buffers - 1, on + int(rng.integers(0, 8))), []).append(Note(pitch, 0.))
+        template = Voice(Oscillator(wave_func=WAVES[int(rng.integers(1, 4))]),
+                         ADSR(.002 + .02 * rng.random(), .005 + .05 * rng.random(), .2 + .7 * rng.random(),
+                              .01 + .05 * rng.random()))
+        if kind == 'poly':
+            cls = type('Poly', (PolyphonicSynthesizer,), {'MAX_VOICES': int(rng.choice([1, 2, 3, 5, 8, 24]))})
+            synth = cls(template)
+        elif kind == 'mono':
+            synth = MonophonicSynthesizer(template, policy=str(rng.choice(['newest', 'oldest', 'lowest', 'highest'])))
+        else:
+            synth = Kick(frequency=30. + 40. * rng.random(), decay=.2 + .6 * rng.random())
+        NoteScript(script) | synth
+        sources.append(synth)
+    if n_src == 1:
+        tail = sources[0]
+    else:
+        tail = StereoMixer() if stereo else Mixer()
+        for s in sources:
+            tail += s
+            if stereo:
+                tail.pannings[-1] = 2. * rng.random() - 1.
+        tail.gains = [float(g) for g in .3 + rng.random(n_src)]
+    if not stereo and rng.random() < .3:
+        tail = tail | make_stage(str(rng.choice(['delay', 'gain', 'tremolo', 'bitcrusher'])), rng)
+    return tail | Dac(nChannels=2 if stereo else 1), n_buffers
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('KLANG_FUZZ_SEEDS', '40'))))
+def test_random_synthesizer_patch_device_equals_host(hip, seed):
+    dac, n_buffers = build_synths(seed)
+    dur = n_buffers * B / 44100. + 1e-9
+    got = np.concatenate(run_klang(dac, offline=True, duration=dur, fadeout=0.))
+    want = np.concatenate(run_klang(build_synths(seed)[0], offline=True, duration=dur, fadeout=0.,
+                                    backend='host'))
+    assert got.shape == want.shape    # (a draw may be silent: a note on and off in one buffer)
+    assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
+    if seed % 4 == 0:    # buffer by buffer on the device: the same samples as prescheduled
+        live = np.concatenate(run_klang(build_synths(seed)[0], offline=True, duration=dur, fadeout=0.,
+                                        lookahead=1))
+        assert np.abs(live - got).max() <= 1e-6 * max(1., np.abs(want).max()), 'seed %d (live)' % seed
