@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kGroup, OCC) void voice_kernel(BankView bk, int fir
     const int first_wave = __builtin_amdgcn_readfirstlane(wave_id);
     const int uniform_wave = __all(wave_id == first_wave) ? first_wave : -1;
     double phase = bk.phase[v];
-    static_assert(!(MOD != MT_NONE && GATED), "gated modulated chains run in voice_mod_kernel");
+    static_assert(!(GATED && (MOD == MT_FREQUENCY || MOD == MT_DUTY)),
+                  "gated chains with an Lfo on frequency / duty cycle run in voice_mod_kernel");
     double mod_freq = 0., mod_scale = 0., mod_offset = 0., mod_phase = 0.;
     int mod_wave = 0;
     bool fm_paired = false;  // wave-uniform: carrier and modulator share a plain wave function
@@ -912,8 +913,11 @@ __global__ __launch_bounds__(kGroup, OCC) void voice_kernel(BankView bk, int fir
                         : np_mod_tau(omega * c_time[kBlock] + start);
         if (MOD != MT_NONE)
             mod_phase = np_mod_tau(mod_omega * c_time[kBlock] + mod_start);
-        if (GATED && !run)
+        if (GATED && !run) {     // an idle voice's oscillator (and its modulator) stay where they are
             phase = start;
+            if (MOD != MT_NONE)
+                mod_phase = mod_start;
+        }
     }
 
     // ---- store state ----------------------------------------------------------------

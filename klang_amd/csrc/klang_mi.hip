@@ -1605,7 +1605,7 @@ static hipError_t dispatch_voice(bool env, bool filt, hipStream_t st, const Bank
                                   n_blocks, span_total, pipe, n_cus, partial, out);
     // audio-rate modulation inputs in a plain [Filter] chain: the fast kernel's forms
     const char *fm_knob = getenv("KLMI_FM_KERNEL");   // tuning knob: 0 = the general kernel
-    if (mod_fast_form(view, plain_chain, MODE) && !(fm_knob && fm_knob[0] == '0'))
+    if (mod_fast_form(view, plain_chain, env, filt, MODE) && !(fm_knob && fm_knob[0] == '0'))
         return launch_fm_kernel(env, filt, MODE, st, view, first, count, block_base, clock_base,
                                 n_blocks, span_total, partial, out);
     // a short Tremolo / Delay / Gain program behind the [Filter]: compiled in

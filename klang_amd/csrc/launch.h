@@ -49,9 +49,10 @@ hipError_t launch_voice_kernel_one_wave(bool env, bool filt, int mode, hipStream
                                         uint32_t clock_base, int n_blocks, int span_total,
                                         float *partial, void *out);
 // voice_kernel<..., MOD> (fm_tu.hip): voices with an audio-rate modulation input (FmOscillator,
-// Lfo -> frequency, Lfo -> duty cycle), ungated, plain [Filter] chain; mod_fast_form says
+// Lfo -> frequency, Lfo -> duty cycle), ungated, plain [Filter] chain -- or gated FM voices
+// without a Filter under a mixer (synthesizers); mod_fast_form says
 // whether the bank and output mode have an instantiation
-bool mod_fast_form(const BankView &view, bool plain_chain, int mode);
+bool mod_fast_form(const BankView &view, bool plain_chain, bool env, bool filt, int mode);
 hipError_t launch_fm_kernel(bool env, bool filt, int mode, hipStream_t st, const BankView &view,
                             int first, int count, int block_base, uint32_t clock_base,
                             int n_blocks, int span_total, float *partial, void *out);

@@ -124,3 +124,48 @@ def test_modulated_fast_forms_vs_general_kernel(hip, ctx, monkeypatch, seed, tar
             np.testing.assert_allclose(x, y, rtol=0, atol=1e-12)
     else:
         assert_same(fast, general)
+
+
+@pytest.mark.parametrize('poly,stereo', [(24, False), (5, True), (1, False)])
+def test_gated_fm_voices_fast_form_vs_general_kernel(hip, ctx, monkeypatch, poly, stereo):
+    """Synthesizer banks whose voices are FmOscillators (non-sine, so every operation is an IEEE
+    basic one): the gated FM form of the fast kernel against voice_mod_kernel (KLMI_FM_KERNEL=0)
+    -- the mixed bus and every piece of state a render leaves, idle voices' carrier and
+    modulator phases among them."""
+    rng = np.random.default_rng(300 + poly)
+    n_inst, nb = 40, 16
+    n = poly * n_inst
+    wave = np.repeat(rng.integers(1, 4, -(-n // 64)), 64)[:n]
+    if n > 128:
+        wave[64:128] = rng.integers(1, 4, 64)     # one wavefront that does not agree (exact form)
+    rows = []
+    for inst in range(n_inst):
+        for _ in range(int(rng.integers(0, 2 * poly + 3))):
+            blk, pitch = int(rng.integers(0, nb - 1)), int(rng.integers(36, 96))
+            f = 440. * 2 ** ((pitch - 69) / 12)
+            rows.append((inst, blk, pitch, 0, .2 + .8 * rng.random(), f))
+            if rng.random() < .8:
+                rows.append((inst, min(nb - 1, blk + int(rng.integers(0, 5))), pitch, 0, 0., f))
+    notes = np.array(rows, dtype=hip.NOTE_DTYPE)
+    fields = [(hip.F_WAVE, wave), (hip.F_ATTACK, .001 + .02 * rng.random(n)),
+              (hip.F_DECAY, .005 + .05 * rng.random(n)), (hip.F_SUSTAIN, .2 + .7 * rng.random(n)),
+              (hip.F_RELEASE, .005 + .05 * rng.random(n)), (hip.F_MOD_FREQUENCY, 20. + 200. * rng.random(n)),
+              (hip.F_MOD_SCALE, 6. * rng.random(n) - 3.), (hip.F_MOD_WAVE, wave),
+              (hip.F_GAIN, .5 + rng.random(n)), (hip.F_PAN, 2. * rng.random(n) - 1.)]
+
+    def run():
+        bank = hip.Bank(ctx, n, has_env=True, poly_voices=poly, mod_target=hip.MOD_FM, stereo=stereo)
+        for field, values in fields:
+            bank.set(field, values)
+        bank.notes(notes)
+        mix = np.concatenate([bank.render(7), bank.render(nb - 7)])
+        state = [bank.get_state(getattr(hip, f)) for f in STATE + ('F_MOD_PHASE', 'F_CURRENT_PITCH',
+                                                                 'F_ROUND_ROBIN')]
+        bank.close()
+        return mix, state
+    fast = run()
+    monkeypatch.setenv('KLMI_FM_KERNEL', '0')
+    general = run()
+    assert np.abs(fast[0]).max() > 1e-3 and np.abs(fast[0] - general[0]).max() <= 2e-7
+    for x, y in zip(fast[1], general[1]):
+        np.testing.assert_array_equal(x, y)

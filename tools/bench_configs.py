@@ -149,13 +149,17 @@ def config3_general(ctx, label, **bank_kw):
                 launches=launches)
 
 
-def config_synth(ctx):
+def config_synth(ctx, fm=False):
     """2,730 PolyphonicSynthesizers x 24 voices (65,520 voices, saw -> ADSR, gated) under one
     Mixer; ~6 notes per instrument sounding, note routing on the device (klmi_bank_notes)."""
     poly, n_inst, n_blocks = 24, 2730, 128
     n = poly * n_inst
-    bank = native.Bank(ctx, n, has_env=True, poly_voices=poly)
+    bank = native.Bank(ctx, n, has_env=True, poly_voices=poly, mod_target=native.MOD_FM if fm else native.MOD_NONE)
     bank.set(native.F_WAVE, np.full(n, native.WAVE_SAWTOOTH))
+    if fm:      # FmOscillator voices: carrier and modulator share the wave function
+        bank.set(native.F_MOD_WAVE, np.full(n, native.WAVE_SAWTOOTH))
+        bank.set(native.F_MOD_FREQUENCY, np.full(n, 110.))
+        bank.set(native.F_MOD_SCALE, np.full(n, 2.5))
     bank.set_mix_divisor(poly * n_inst)
     rng = np.random.default_rng(5)
     per_inst, runs = 40, 5
@@ -176,9 +180,10 @@ def config_synth(ctx):
     best, med = timed(lambda: bank.render(n_blocks))
     ms, launches = bank.last_kernel_ms()
     units = n * n_blocks * B
-    return dict(config='synthesizers: %d PolyphonicSynthesizers x %d voices (saw -> ADSR, gated) -> '
+    return dict(config='synthesizers: %d PolyphonicSynthesizers x %d voices (%s -> ADSR, gated) -> '
                        'Mixer, %d notes per synthesizer and render, device-side routing, %d blocks'
-                       % (n_inst, poly, per_inst, n_blocks),
+                       % (n_inst, poly, 'FmOscillator(saw)' if fm else 'saw', per_inst, n_blocks),
+                knobs={k: v for k, v in os.environ.items() if k.startswith('KLMI_')},
                 value=units / med, unit='voice-samples/s', wall_ms=med * 1e3, kernel_ms=ms,
                 launches=launches)
 
@@ -248,6 +253,8 @@ def main():
                                          native.FX_SUBSAMPLE])
         elif w == 'synth':
             r = config_synth(ctx)
+        elif w == 'synthfm':
+            r = config_synth(ctx, fm=True)
         elif w == '4big':
             r = config4(ctx, 16384, 128)
         elif w == '4f32':
