@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
     constexpr int FIRST_STAGE = FILT ? 1 : 0;   // the Filter, when there is one, is stage 0
     constexpr int TREM = fx_program_find(PROG, FX_TREMOLO);
     constexpr int DELAY = fx_program_find(PROG, FX_DELAY);
+    constexpr int RING = fx_program_find(PROG, FX_RINGMOD);
     static_assert(NSTAGE >= 1, "plain chains run in voice_kernel");
 
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -138,6 +139,21 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
         trem_z = bk.fx_state[(size_t)(2 * (FIRST_STAGE + TREM) + 1) * n + v];
     }
     const double trem_floor = 1. - trem_depth;
+    // RingModulator (effects.py:618-662): an Lfo (its wave function per voice) sweeps the
+    // frequency of a sine modulator; frequency, rate, amount, dryWet, Lfo wave
+    double ring_freq = 0., ring_rate = 0., ring_amount = 0., ring_dw = 0.;
+    double ring_lfo_phase = 0., ring_phase = 0.;
+    int ring_wave = 0;
+    if constexpr (RING >= 0) {
+        const double *par = bk.fx_par + (size_t)((FIRST_STAGE + RING) * kFxSlots) * n + v;
+        ring_freq = par[0], ring_rate = par[n], ring_amount = par[2 * n], ring_dw = par[3 * n];
+        ring_wave = (int)par[4 * n];
+        ring_lfo_phase = bk.fx_state[(size_t)(2 * (FIRST_STAGE + RING)) * n + v];
+        ring_phase = bk.fx_state[(size_t)(2 * (FIRST_STAGE + RING) + 1) * n + v];
+    }
+    const double ring_dry = 1. - ring_dw;
+    const int first_ring_wave = __builtin_amdgcn_readfirstlane(ring_wave);
+    const int uniform_ring_wave = __all(ring_wave == first_ring_wave) ? first_ring_wave : -1;
     // Delay (effects.py:136-174): lines tiled by absolute time (bank_kernels.h delay_read8);
     // the position is carried only as the state the reference's RingBuffer would report
     int delay_pos = 0, delay_len = 1;
@@ -225,6 +241,16 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
         const double trem_start = trem_phase;
         const bool fast_trem =
             TREM >= 0 && __all(trem_omega >= 0. && trem_start >= 0. && trem_omega * t_end + trem_start < 1e9);
+        const double ring_omega = kTau * ring_rate;    // the Lfo: Oscillator.sample, scalar rate
+        const double ring_lfo_start = ring_lfo_phase, ring_start = ring_phase;
+        double ring_running = 0.;                      // np.cumsum of the modulator's frequencies
+        // wave-uniform: the Lfo's and the modulator's phase arguments of this block are >= 0 and
+        // < 1e9 (the modulator's frequency ring_freq + amount * [-1, 1] never turns negative)
+        const bool fast_ring =
+            RING >= 0 && uniform_ring_wave >= W_SINE && uniform_ring_wave <= W_TRIANGLE &&
+            __all(ring_omega >= 0. && ring_lfo_start >= 0. && ring_omega * t_end + ring_lfo_start < 1e9 &&
+                  ring_freq - fabs(ring_amount) >= 0. && ring_start >= 0. &&
+                  (kTau * kDt) * kBlock * (ring_freq + fabs(ring_amount)) + ring_start < 1e9);
 
         // ---- region 1: eight oscillator samples ------------------------------------------
         auto osc_group = [&](const Time8 &tt, int sample0, double (&osc)[G]) {
@@ -369,6 +395,74 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
                     trem_exact = !fast_trem || __builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) != 0;
                 }
 
+                // the RingModulator's sine does not depend on the signal either: Lfo -> frequency
+                // -> running sum -> phase (the array branch of sample_phase, oscillators.py:61-64)
+                double rm[G];
+                if constexpr (RING >= 0) {
+                    const bool first_group = c == 0 && i8 == 0;
+                    const double running0 = ring_running;
+                    bool exact = !fast_ring;
+                    if (!exact) {
+                        uint32_t hi_max = 0;
+                        double lp[G], f[G];
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const double la = ring_omega * tt.t[j] + ring_lfo_start;
+                            const double k = floor(la * kInvTau);
+                            lp[j] = __builtin_fma(-k, kTau, la);
+                            hi_max = max(hi_max, (uint32_t)__double2hiint(lp[j]));
+                        }
+                        switch (uniform_ring_wave) {
+                        case W_SINE:
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                f[j] = wave_eval<true>(W_SINE, lp[j], kPi);
+                            break;
+                        case W_SQUARE:
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                f[j] = wave_eval<true>(W_SQUARE, lp[j], kPi);
+                            break;
+                        case W_SAWTOOTH:
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                f[j] = wave_eval<true>(W_SAWTOOTH, lp[j], kPi);
+                            break;
+                        default:
+#pragma unroll
+                            for (int j = 0; j < G; ++j)
+                                f[j] = wave_eval<true>(W_TRIANGLE, lp[j], kPi);
+                            break;
+                        }
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const double fj = ring_freq + ring_amount * f[j];
+                            const bool first_sample = first_group && j == 0;
+                            const double arg = first_sample ? ring_start
+                                                            : (kTau * kDt) * ring_running + ring_start;
+                            const double k = floor(arg * kInvTau);
+                            const double ph = __builtin_fma(-k, kTau, arg);
+                            hi_max = max(hi_max, (uint32_t)__double2hiint(ph));
+                            ring_running = first_sample ? fj : ring_running + fj;
+                            rm[j] = sin_wrapped(ph);
+                        }
+                        exact = __builtin_amdgcn_ballot_w64(hi_max >= kTauHighWord) != 0;
+                    }
+                    if (__builtin_expect(exact, 0)) {
+                        ring_running = running0;
+#pragma unroll
+                        for (int j = 0; j < G; ++j) {
+                            const double lp = np_mod_tau(ring_omega * tt.t[j] + ring_lfo_start);
+                            const double fj = ring_freq + ring_amount * wave_eval<true>(ring_wave, lp, kPi);
+                            const bool first_sample = first_group && j == 0;
+                            const double arg = first_sample ? ring_start
+                                                            : (kTau * kDt) * ring_running + ring_start;
+                            ring_running = first_sample ? fj : ring_running + fj;
+                            rm[j] = wave_eval<true>(W_SINE, np_mod_tau(arg), kPi);
+                        }
+                    }
+                }
+
                 if (__builtin_expect(redo != 0, 0)) {
                     // some lane's envelope switches stage in these 8 samples: the exact state
                     // machine, from the uncommitted state
@@ -408,6 +502,10 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
 #pragma unroll
                         for (int j = 0; j < G; ++j)
                             y[j] = tg[j] * y[j];
+                    } else if (kind == FX_RINGMOD) {   // math.py:68-75 blend(x, am * x, dryWet)
+#pragma unroll
+                        for (int j = 0; j < G; ++j)
+                            y[j] = ring_dry * y[j] + ring_dw * (rm[j] * y[j]);
                     } else if (kind == FX_GAIN) {      // effects.py:67-70
 #pragma unroll
                         for (int j = 0; j < G; ++j)
@@ -493,6 +591,10 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
             phase = np_mod_tau(omega * t_end + start);
         if constexpr (TREM >= 0)
             trem_phase = np_mod_tau(trem_omega * t_end + trem_start);
+        if constexpr (RING >= 0) {
+            ring_lfo_phase = np_mod_tau(ring_omega * t_end + ring_lfo_start);
+            ring_phase = np_mod_tau((kTau * kDt) * ring_running + ring_start);
+        }
         if constexpr (DELAY >= 0)
             delay_pos = (delay_pos + kBlock) % delay_len;
     }
@@ -518,6 +620,10 @@ __global__ __launch_bounds__(kGroup) void voice_fx_kernel(BankView bk, int first
         }
         if constexpr (DELAY >= 0)
             bk.fx_state[(size_t)(2 * (FIRST_STAGE + DELAY)) * n + v] = (double)delay_pos;
+        if constexpr (RING >= 0) {
+            bk.fx_state[(size_t)(2 * (FIRST_STAGE + RING)) * n + v] = ring_lfo_phase;
+            bk.fx_state[(size_t)(2 * (FIRST_STAGE + RING) + 1) * n + v] = ring_phase;
+        }
         bk.ev_cursor[v] = ev_i - bk.ev_offset[v];
     }
 }

@@ -11,8 +11,10 @@ namespace klmi {
 #endif
 #if KLMI_FX_HALF == 0
 hipError_t upload_time_table_fx(const double *t)
-#else
+#elif KLMI_FX_HALF == 1
 hipError_t upload_time_table_fx_b(const double *t)
+#else
+hipError_t upload_time_table_fx_c(const double *t)
 #endif
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_time), t, sizeof(double) * kTimeSlots);
@@ -21,8 +23,9 @@ hipError_t upload_time_table_fx_b(const double *t)
 // Tremolo / Delay / element-wise stages behind the optional Filter, in the orders the
 // reference's patches use them (examples/tempo_aware_effects.py, arpeggiator_demo.py,
 // aeolian_arp.py) and the short all-element-wise chains (Gain -> Bitcrusher -> Subsampler ...).
-// FX_ELEM: the slot that stands for any element-wise kind (fx_kernels.h).  The list is
-// split over two objects (KLMI_FX_HALF 0 / 1) that compile side by side.
+// FX_ELEM: the slot that stands for any element-wise kind (fx_kernels.h).  List C: a
+// RingModulator with element-wise stages around it.  The list is split over three objects
+// (KLMI_FX_HALF 0 / 1 / 2) that compile side by side.
 #define KLMI_FX_PROGRAMS_A(X)                \
     X(fx_program(FX_TREMOLO))                \
     X(fx_program(FX_DELAY))                  \
@@ -40,13 +43,20 @@ hipError_t upload_time_table_fx_b(const double *t)
     X(fx_program(FX_ELEM, FX_DELAY))         \
     X(fx_program(FX_DELAY, FX_ELEM))         \
     X(fx_program(FX_ELEM, FX_DELAY, FX_ELEM))
-#define KLMI_FX_PROGRAMS(X) KLMI_FX_PROGRAMS_A(X) KLMI_FX_PROGRAMS_B(X)
+#define KLMI_FX_PROGRAMS_C(X)                \
+    X(fx_program(FX_RINGMOD))                \
+    X(fx_program(FX_RINGMOD, FX_ELEM))       \
+    X(fx_program(FX_ELEM, FX_RINGMOD))       \
+    X(fx_program(FX_RINGMOD, FX_ELEM, FX_ELEM))
 #if KLMI_FX_HALF == 0
 #define KLMI_FX_PROGRAMS_HERE(X) KLMI_FX_PROGRAMS_A(X)
 #define KLMI_FX_LAUNCH launch_fx_kernel_a
-#else
+#elif KLMI_FX_HALF == 1
 #define KLMI_FX_PROGRAMS_HERE(X) KLMI_FX_PROGRAMS_B(X)
 #define KLMI_FX_LAUNCH launch_fx_kernel_b
+#else
+#define KLMI_FX_PROGRAMS_HERE(X) KLMI_FX_PROGRAMS_C(X)
+#define KLMI_FX_LAUNCH launch_fx_kernel_c
 #endif
 
 static bool fx_elementwise(int kind)
@@ -83,6 +93,7 @@ uint32_t fx_program_of(const BankView &view, bool filt, int mode)
     if (generic == (P)) \
         return generic;
     KLMI_FX_PROGRAMS_B(X)
+    KLMI_FX_PROGRAMS_C(X)
 #undef X
     return 0;
 }
@@ -163,6 +174,10 @@ hipError_t launch_fx_kernel_b(uint32_t prog, bool env, bool filt, int mode, hipS
                               const BankView &view, int first, int count, int block_base,
                               uint32_t clock_base, int n_blocks, int span_total, float *partial,
                               void *out);
+hipError_t launch_fx_kernel_c(uint32_t prog, bool env, bool filt, int mode, hipStream_t st,
+                              const BankView &view, int first, int count, int block_base,
+                              uint32_t clock_base, int n_blocks, int span_total, float *partial,
+                              void *out);
 
 hipError_t launch_fx_kernel(uint32_t prog, bool env, bool filt, int mode, hipStream_t st,
                             const BankView &view, int first, int count, int block_base,
@@ -174,6 +189,12 @@ hipError_t launch_fx_kernel(uint32_t prog, bool env, bool filt, int mode, hipStr
         return launch_fx_kernel_a(prog, env, filt, mode, st, view, first, count, block_base, \
                                   clock_base, n_blocks, span_total, partial, out);
     KLMI_FX_PROGRAMS_A(X)
+#undef X
+#define X(P) \
+    if (prog == (P)) \
+        return launch_fx_kernel_c(prog, env, filt, mode, st, view, first, count, block_base, \
+                                  clock_base, n_blocks, span_total, partial, out);
+    KLMI_FX_PROGRAMS_C(X)
 #undef X
     return launch_fx_kernel_b(prog, env, filt, mode, st, view, first, count, block_base, clock_base,
                               n_blocks, span_total, partial, out);

@@ -285,6 +285,8 @@ extern "C" int klmi_ctx_create(int device, void *stream, klmi_ctx **out)
         e = upload_time_table_fx(t);
     if (e == hipSuccess)
         e = upload_time_table_fx_b(t);
+    if (e == hipSuccess)
+        e = upload_time_table_fx_c(t);
     if (e == hipSuccess) {
         void *p = nullptr;  // this device's copy of the scratch array (the device is current)
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));

@@ -37,6 +37,7 @@ hipError_t upload_time_table_mod(const double *t);
 hipError_t upload_time_table_fm(const double *t);
 hipError_t upload_time_table_fx(const double *t);
 hipError_t upload_time_table_fx_b(const double *t);
+hipError_t upload_time_table_fx_c(const double *t);
 
 // grid = ceil(count / 256) workgroups; `mode` is an OutMode
 hipError_t launch_voice_kernel(bool env, bool filt, bool gated, int mode, hipStream_t st,

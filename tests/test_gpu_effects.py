@@ -348,3 +348,62 @@ def test_effect_argument_errors(hip, ctx):
         bank.set(hip.F_FX(2, 0), [1., 1.])                              # no such stage
     with pytest.raises(hip.NativeError):
         bank.get_state(hip.F_FX_STATE(5, 0))
+
+
+@pytest.mark.parametrize('program,has_filter', [('R', True), ('R', False), ('RG', True), ('BR', False),
+                                                ('RBS', True)])
+def test_compiled_ring_modulator_programs(hip, ctx, oracle, monkeypatch, program, has_filter):
+    """RingModulator (effects.py:618-662) with element-wise stages around it, compiled into
+    voice_fx_kernel: float64 streams and all state bit for bit equal to the stage interpreter's
+    (KLMI_FX_KERNEL=0: the same operations, the same sine polynomial), and within 1e-12 of the
+    oracle (libm's sine).  Lfo wave functions that differ from wavefront to wavefront, one mixed
+    wavefront, some negative Lfo rates and sweeps below zero (the exact remainder)."""
+    n, nb = 64 * 6 + 11, 10
+    rng = np.random.default_rng(900 + len(program) + 5 * has_filter)
+    patch = P.polyphonic_saw_patch(n_voices=n, n_blocks=nb, off_base=3, off_span=5)
+    patch['has_filter'] = has_filter
+    patch['wave'] = (np.repeat(np.arange(-(-n // 64)) % 3 + 1, 64)[:n]).astype(np.int32)
+    lfo_wave = np.repeat(np.arange(-(-n // 64)) % 4, 64)[:n]
+    lfo_wave[64:128] = rng.integers(0, 4, 64)
+    rate = .5 + 6. * rng.random(n)
+    rate[200:210] = -rate[200:210]
+    amount = 40. * rng.random(n)
+    amount[300:320] = 900.                      # sweeps the modulator's frequency below zero
+    make = {'R': lambda: (hip.FX_RINGMOD, 100. + 500. * rng.random(n), rate, amount, rng.random(n), lfo_wave),
+            'G': lambda: (hip.FX_GAIN, 1.5 * rng.random(n)),
+            'B': lambda: (hip.FX_BITCRUSH, rng.integers(0, 16, n)),
+            'S': lambda: (hip.FX_SUBSAMPLE, 2 ** rng.integers(1, 8, n))}
+    stages = ([(hip.FX_FILTER,)] if has_filter else []) + [make[k]() for k in program]
+    table, grid = library_table(hip)
+    from tests.helpers import oracle_bank_from_patch
+    ob = oracle_bank_from_patch(oracle, patch, table, grid)
+    ob.set_effects(stages)
+    want_mix, want_voices = ob.render(nb, patch.events, want_voices=True)
+
+    def run():
+        hb = hip.Bank(ctx, n, has_env=True, has_filter=has_filter, effects=[s[0] for s in stages])
+        hb.load_patch(patch)
+        for s, st in enumerate(stages):
+            for k, p in enumerate(st[1:]):
+                hb.set(hip.F_FX(s, k), np.broadcast_to(np.asarray(p, dtype=float), (n,)))
+        voices = hb.render_voices(nb, f64=True)
+        mix = np.concatenate([hb.render(4), hb.render(nb - 4)])
+        s_ring = [s for s, st in enumerate(stages) if st[0] == hip.FX_RINGMOD][0]
+        state = [hb.get_state(hip.F_PHASE), hb.get_state(hip.F_FX_STATE(s_ring, 0)),
+                 hb.get_state(hip.F_FX_STATE(s_ring, 1))]
+        hb.close()
+        return voices, mix, state, s_ring
+    compiled = run()
+    monkeypatch.setenv('KLMI_FX_KERNEL', '0')
+    general = run()
+    np.testing.assert_array_equal(compiled[0], general[0])
+    np.testing.assert_array_equal(compiled[1], general[1])
+    for a, b in zip(compiled[2], general[2]):
+        np.testing.assert_array_equal(a, b)
+    crushed = 'B' in program     # a quantiser turns an ulp at a step into a whole step
+    if not crushed:
+        assert np.abs(compiled[0] - want_voices).max() <= 1e-12
+    assert np.abs(compiled[1][:, 0, :] - want_mix[:, 0, :]).max() <= (1e-3 if crushed else 1e-6)
+    s_ring = compiled[3]
+    np.testing.assert_allclose(compiled[2][1], ob.fx_state[s_ring, 0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(compiled[2][2], ob.fx_state[s_ring, 1], rtol=0, atol=1e-9)

@@ -133,6 +133,12 @@ def config3_general(ctx, label, **bank_kw):
             label += ' [%s times]' % mode
         elif kind == native.FX_GAIN:
             bank.set(native.F_FX(s, 0), rng.random(n))
+        elif kind == native.FX_RINGMOD:     # frequency, rate, amount, dryWet, Lfo wave (square)
+            bank.set(native.F_FX(s, 0), 200. + 600. * rng.random(n))
+            bank.set(native.F_FX(s, 1), .5 + 4. * rng.random(n))
+            bank.set(native.F_FX(s, 2), 30. * rng.random(n))
+            bank.set(native.F_FX(s, 3), rng.random(n))
+            bank.set(native.F_FX(s, 4), np.full(n, float(native.WAVE_SQUARE)))
         elif kind == native.FX_BITCRUSH:
             bank.set(native.F_FX(s, 0), rng.integers(4, 12, n).astype(float))
         elif kind == native.FX_SUBSAMPLE:
@@ -251,6 +257,9 @@ def main():
             r = config3_general(ctx, 'Filter -> Gain -> Bitcrusher -> Subsampler',
                                 effects=[native.FX_FILTER, native.FX_GAIN, native.FX_BITCRUSH,
                                          native.FX_SUBSAMPLE])
+        elif w == '3ring':
+            r = config3_general(ctx, 'Filter -> RingModulator -> Gain',
+                                effects=[native.FX_FILTER, native.FX_RINGMOD, native.FX_GAIN])
         elif w == 'synth':
             r = config_synth(ctx)
         elif w == 'synthfm':
