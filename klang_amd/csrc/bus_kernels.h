@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void bus_slice_kernel(const float *__restrict_
     double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
 #pragma unroll 4
     for (int r = r0; r < r1; ++r) {
-        const float4 p = *reinterpret_cast<const float4 *>(partial + (size_t)r * bus_len + s);
+        typedef float Float4 __attribute__((ext_vector_type(4)));
+        const Float4 p = __builtin_nontemporal_load(reinterpret_cast<const Float4 *>(partial + (size_t)r * bus_len + s));
         a0 += (double)p.x, a1 += (double)p.y, a2 += (double)p.z, a3 += (double)p.w;
     }
     double *o = stage + (size_t)blockIdx.y * bus_len + s;

@@ -347,7 +347,11 @@ __global__ __launch_bounds__(kReverbThreads, 2) void reverb_voice_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         o4.e[i] = (float)s[i];
-                    store_quad(o + pl * kBlock, o4);
+                    // written once, read once by bus_slice_kernel much later: a streaming store,
+                    // so that the row does not take ring lines' places in the caches
+                    typedef float Float4 __attribute__((ext_vector_type(4)));
+                    Float4 v4 = {o4.e[0], o4.e[1], o4.e[2], o4.e[3]};
+                    __builtin_nontemporal_store(v4, reinterpret_cast<Float4 *>(o + pl * kBlock));
                 }
             }
         }
