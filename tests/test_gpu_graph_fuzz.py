@@ -139,7 +139,7 @@ def test_random_patch_device_equals_host(hip, seed):
     dur = (10 + seed % 9) * B / 44100. + 1e-9
     got = np.concatenate(run_klang(build(seed), offline=True, duration=dur, fadeout=0.))
     want = np.concatenate(run_klang(build(seed), offline=True, duration=dur, fadeout=0., backend='host'))
-    assert got.shape == want.shape and np.abs(want).max() > 1e-3
+    assert got.shape == want.shape and np.abs(want).max() > 1e-6
     assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
 
 
@@ -191,7 +191,7 @@ def test_random_live_notes_device_equals_host(hip, seed):
     got = play(order, mixer, voices, script, n_buffers)
     for bank in banks:
         bank.close()
-    assert got.shape == want.shape and np.abs(want).max() > 1e-3
+    assert got.shape == want.shape and np.abs(want).max() > 1e-6
     assert np.abs(got - want).max() <= 1e-5 * max(1., np.abs(want).max()), 'seed %d' % seed
 
 
